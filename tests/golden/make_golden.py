@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Captures the golden vectors under tests/golden/ — run ONLY in the build
+container (needs /root/reference and the locally installed ``transformers``;
+neither exists on the GPU box, and nothing of them is committed: the outputs
+are data — inputs' seeds and expected outputs).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Produces
+  encoder_b32_seed1234.npz   64 synthetic frames through
+                             transformers.CLIPModel(CLIPConfig()) carrying the
+                             build's seeded weights: L2-normalised [64,512] fp32
+                             embeddings, the un-normalised features, and a
+                             checksum of the frames/weights they came from.
+  knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
+                             OptimizedHNSWIndex, random.seed(0)) over 1,000
+                             seeded vectors: its levels, entry point and graph,
+                             and its top-5 / top-10 result lists for the 64
+                             embeddings above at ef_search=50 (default,
+                             approximate) and ef_search=1000 (exhaustive).
+"""
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+FRAME_SEED = 20250824
+WEIGHT_SEED = 1234
+INDEX_SEED = 7
+N_FRAMES, N_INDEX = 64, 1000
+
+
+def synth_frames(n, seed=FRAME_SEED):
+    # the reference's own synthetic-frame convention: randint(0,255,(224,224,3),uint8)
+    # (reference src/video_search_system.py:556-557)
+    return np.random.default_rng(seed).integers(0, 255, (n, 224, 224, 3), dtype=np.uint8)
+
+
+def capture_encoder():
+    import torch
+    from transformers import CLIPConfig, CLIPModel
+    from video_quierer_amd.weights import VIT_B_32, seeded_weights
+
+    torch.manual_seed(0)
+    W = seeded_weights(VIT_B_32, WEIGHT_SEED)
+    model = CLIPModel(CLIPConfig()).eval()          # ViT-B/32 defaults, no hub access
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    frames = synth_frames(N_FRAMES)
+    # _preprocess_image (reference feature_extractor.py:105-116) at 224x224:
+    # BGR->RGB, HWC->CHW, /255, (x-mean)/std
+    x = torch.from_numpy(np.ascontiguousarray(frames[..., ::-1])).permute(0, 3, 1, 2).float() / 255.0
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    with torch.no_grad():
+        out = model.get_image_features(x)
+        feats = out.pooler_output if hasattr(out, "pooler_output") else out   # tf 5.x vs 4.x
+        emb = torch.nn.functional.normalize(feats, p=2, dim=1)
+    wsum = hashlib.sha256()
+    for k in sorted(W):
+        wsum.update(W[k].tobytes())
+    np.savez_compressed(
+        os.path.join(HERE, "encoder_b32_seed1234.npz"),
+        embeddings=emb.numpy().astype(np.float32), features=feats.numpy().astype(np.float32),
+        frame_seed=FRAME_SEED, weight_seed=WEIGHT_SEED,
+        frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest(),
+        weights_sha256=wsum.hexdigest())
+    return emb.numpy().astype(np.float32)
+
+
+def capture_knn(queries):
+    sys.path.insert(0, "/root/reference/src")
+    from indexes.hnsw import OptimizedHNSWIndex        # the real reference
+
+    vecs = np.random.default_rng(INDEX_SEED).standard_normal((N_INDEX, 512)).astype(np.float32)
+    random.seed(0)
+    idx = OptimizedHNSWIndex(dimension=512)            # defaults: M=16 efC=200 ef=50
+    idx.add_batch(list(vecs), list(range(N_INDEX)))
+    stored = np.stack([idx.data[i] for i in range(N_INDEX)]).astype(np.float32)
+    levels = np.array([idx.levels[i] for i in range(N_INDEX)], dtype=np.int32)
+    edges = []                                          # (level, a, b) with a in adj of... directed
+    for lv, nodes in idx.graph.items():
+        for a, nbrs in nodes.items():
+            for b in nbrs:
+                edges.append((int(lv), int(a), int(b)))
+    edges = np.array(sorted(edges), dtype=np.int32)
+    out = dict(index_seed=INDEX_SEED, stored=stored, levels=levels, edges=edges,
+               entry_point=np.int32(idx.entry_point))
+    for ef in (50, N_INDEX):
+        idx.ef_search = ef
+        for k in (5, 10):
+            res = [idx.search(q, k) for q in queries]
+            out[f"ids_ef{ef}_k{k}"] = np.array([[r["id"] for r in rr] for rr in res], dtype=np.int32)
+            out[f"dist_ef{ef}_k{k}"] = np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32)
+            out[f"score_ef{ef}_k{k}"] = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32)
+            assert all(type(r["distance"]) is np.float32 for rr in res for r in rr)
+    np.savez_compressed(os.path.join(HERE, "knn_cfg1.npz"), **out)
+
+
+if __name__ == "__main__":
+    emb = capture_encoder()
+    capture_knn(emb)
+    print("golden vectors written to", HERE)
