@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): frames/s of the CLIP ViT-B/32 encode on
+batch-256 synthetic 224x224 RGB frames (configs[1]), plus queries/s of the
+top-10 scan over a 1M x 512 matrix (configs[2]) as a secondary object.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 is launched by torch.distributed.run (one rank per GPU, RCCL); every rank
+encodes its own frame shard (weak scaling) and all ranks all-gather the
+per-shard embeddings each step (the path's one exchange step).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 256
+FLOP_PER_FRAME = 2 * 4_408_811_520          # 8.818 GFLOP / frame (full 50-token forward)
+PEAK_BF16 = 2.5e15                          # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_FP16 = 2.5e15
+PEAK_HBM = 8.0e12
+METRIC = "frames/sec CLIP ViT-B/32 encode + queries/sec top-10 over 1M×512 embeds"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--search-rows", type=int, default=1_000_000)
+    ap.add_argument("--search-queries", type=int, default=10_000)
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=64)
+    return ap.parse_args()
+
+
+def gemm_flops(cls, rows, cfg):
+    h, m, pk = cfg.hidden, cfg.mlp, cfg.patch_k
+    prow = rows // cfg.tokens * cfg.patches
+    return {
+        "gemm_patch_embed": 2 * prow * h * pk,
+        "gemm_qkv": 2 * rows * 3 * h * h,
+        "gemm_out_proj_residual": 2 * rows * h * h,
+        "gemm_fc1_quickgelu": 2 * rows * m * h,
+        "gemm_fc2_residual": 2 * rows * h * m,
+    }.get(cls)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from video_quierer_amd import _lib
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    from video_quierer_amd.weights import VIT_B_32, seeded_weights
+
+    _lib.init(local)
+    cfg = VIT_B_32
+    weights = seeded_weights(cfg, 1234)
+    enc = VitEncoder(cfg, weights, max_batch=BATCH, device=local)
+    stream = torch.cuda.current_stream(dev)
+    enc.set_stream(stream.cuda_stream)      # same stream as torch/RCCL: no host sync between encode and all-gather
+
+    # synthetic frames, device resident (the reference's randint(0,255) convention), 4 distinct batches per rank
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20250824 + rank)
+    pool = [torch.randint(0, 255, (BATCH, 224, 224, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(4)]
+    emb = torch.empty((BATCH, cfg.proj_dim), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i):
+        enc.encode_device(pool[i % len(pool)].data_ptr(), BATCH, emb.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, emb)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_per_s = world * args.steps * BATCH / elapsed
+
+    out = {
+        "metric": METRIC, "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: batch-256 ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
+                               "device-resident input (H2D excluded), seeded random-init weights",
+                   "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world,
+                   "parallelism": f"dp{world} (frame shards; RCCL all-gather of embeddings per step)" if world > 1 else "single GPU"},
+        "encode_mfma_frac_whole_pass": frames_per_s / world * FLOP_PER_FRAME / PEAK_BF16,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: per-class HIP-event timing on the launch stream ----
+        torch.cuda.synchronize(dev)
+        enc.profile_begin()
+        psteps = 3
+        for i in range(psteps):
+            enc.encode_device(pool[i % len(pool)].data_ptr(), BATCH, emb.data_ptr())
+        prof = enc.profile_end()
+        total_ms = sum(v["ms"] for v in prof.values())
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        rows = BATCH * cfg.tokens
+        fl = gemm_flops(dom, rows, cfg)
+        avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
+        if fl is not None:
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12,
+                               "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_BF16, "traffic": None,
+                               "avg_launch_ms": avg_ms, "flops_per_launch": fl}
+        else:
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                               "frac": None, "traffic": None, "avg_launch_ms": avg_ms}
+        out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / psteps, "launches_per_step": v["launches"] // psteps,
+                                     "share": v["ms"] / total_ms,
+                                     **({"tflops": gemm_flops(k, rows, cfg) * v["launches"] / (v["ms"] * 1e-3) / 1e12}
+                                        if gemm_flops(k, rows, cfg) and v["ms"] > 0 else {})}
+                                 for k, v in prof.items()}
+
+    # ---- secondary: queries/s, top-10 over a row-sharded 1M x 512 matrix (configs[2]) ----
+    if not args.no_search:
+        n_rows, nq, k = args.search_rows // world, args.search_queries, 10
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(7 + rank)
+        idx = OptimizedHNSWIndex(dimension=512, device=local)
+        idx.set_stream(stream.cuda_stream)
+        for c0 in range(0, n_rows, 250_000):
+            c = min(250_000, n_rows - c0)
+            block = torch.randn((c, 512), dtype=torch.float32, device=dev, generator=g2)
+            idx.add_device(block.data_ptr(), c, range(c0, c0 + c), normalize=True)
+            torch.cuda.synchronize(dev)
+        g3 = torch.Generator(device=dev)
+        g3.manual_seed(99)                                      # same queries on every rank
+        q = torch.randn((nq, 512), dtype=torch.float32, device=dev, generator=g3)
+        q = q / q.norm(dim=1, keepdim=True)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        all_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev) if world > 1 else None
+        all_dd = torch.empty((world, nq, k), dtype=torch.float32, device=dev) if world > 1 else None
+
+        def search_step():
+            idx.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
+            if world > 1:       # exchange step: all-gather of local top-k, merged with the same (distance,id) order
+                dist.all_gather_into_tensor(all_ids, ids + rank * n_rows)
+                dist.all_gather_into_tensor(all_dd, dd)
+                cat_d = all_dd.permute(1, 0, 2).reshape(nq, world * k)
+                cat_i = all_ids.permute(1, 0, 2).reshape(nq, world * k)
+                order = torch.argsort(cat_d, dim=1, stable=True)[:, :k]   # rank-major concat => ties keep the smaller global id
+                return torch.gather(cat_i, 1, order), torch.gather(cat_d, 1, order)
+            return ids, dd
+
+        search_step()
+        fence()
+        s_steps = 3
+        t0 = time.perf_counter()
+        for _ in range(s_steps):
+            search_step()
+        fence()
+        s_el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([s_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_el = float(t.item())
+        qps = s_steps * nq / s_el
+        srch = {"value": qps, "unit": "queries/s", "rows": n_rows * world, "queries": nq, "k": k,
+                "ms_per_batch": 1e3 * s_el / s_steps, "mode": "exact fp32-master scan (fp64-chain dot)",
+                "sharding": f"{world} row shards + all-gather of local top-k" if world > 1 else "single GPU"}
+        if rank == 0:
+            idx.profile_begin()
+            idx.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
+            sp = idx.profile_end()
+            srch["kernel_classes"] = {k_: v for k_, v in sp.items() if v["launches"]}
+            srch["last_search_stats"] = idx.last_search_stats()
+        out["search"] = srch
+        idx.close()
+
+    # ---- CPU baseline: the fp32 oracle (a port of the reference's CPU path) on a bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import clip_vit_oracle
+        torch.set_num_threads(os.cpu_count() or 1)
+        sample = np.random.default_rng(20250824).integers(0, 255, (args.cpu_frames, 224, 224, 3), dtype=np.uint8)
+        clip_vit_oracle.encode_frames(sample[:8], weights, batch_size=8)          # warm the thread pool
+        t0 = time.perf_counter()
+        clip_vit_oracle.encode_frames(sample, weights, batch_size=32)             # reference default batch_size=32
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": args.cpu_frames / ct, "unit": "frames/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{args.cpu_frames} synthetic frames, batch 32, fp32 torch-CPU oracle "
+                                         f"(oracle/clip_vit_oracle.py), preprocessing included, {ct:.2f}s"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

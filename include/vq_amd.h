@@ -1,0 +1,153 @@
+/* libvq_amd — C ABI of the MI355X (gfx950) frame-embedding + exact cosine k-NN path.
+ *
+ * The reference (adhney/video-quierer) has no FFI boundary: its boundary for this
+ * path is two Python classes,
+ *   FeatureExtractor        reference src/core/feature_extractor.py:21-258
+ *   HNSWIndex / OptimizedHNSWIndex   reference src/indexes/hnsw.py:19-528
+ * constructed at reference src/video_search_system.py:65-69 and :79-89.  The
+ * build's same-named Python classes (video-quierer_amd/core/feature_extractor.py,
+ * video-quierer_amd/indexes/hnsw.py) bind exactly the entry points below with
+ * ctypes; INTEGRATION.md shows the binding.  Each group names the reference
+ * method(s) it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative code; the message is in
+ *     vq_last_error() (thread-local).  Wrappers raise (reference convention:
+ *     log + raise, feature_extractor.py:175-177, hnsw.py:353-354).
+ *   - the caller owns every host buffer (C-contiguous); the library owns device
+ *     memory behind the opaque handles; *_destroy frees it.
+ *   - handles are safe to share between threads (one mutex + one HIP stream per
+ *     handle); ctypes releases the GIL during calls.
+ *   - "_device" variants take device pointers (e.g. torch.Tensor.data_ptr()) and
+ *     are asynchronous on the handle's stream until *_synchronize.
+ *   - no torch / STL types cross this boundary.
+ */
+#ifndef VQ_AMD_H
+#define VQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ_OK 0
+#define VQ_ERR_INVALID (-1)
+#define VQ_ERR_HIP (-2)
+#define VQ_ERR_STATE (-3)
+#define VQ_ERR_OOM (-4)
+
+/* ---- library ------------------------------------------------------------- */
+/* Binds the calling process to one GPU (reference: device pick in
+ * FeatureExtractor.__init__, feature_extractor.py:41-44).  Fails when no gfx950
+ * device is visible: there is no CPU fallback. */
+int vq_init(int device_ordinal);
+int vq_device_count(int* count);
+const char* vq_last_error(void);
+const char* vq_version(void);
+
+/* ---- encoder: FeatureExtractor._load_model / extract_batch ----------------- */
+typedef struct vq_encoder vq_encoder;
+
+typedef struct vq_vit_config {
+    int32_t image_size;   /* 224 */
+    int32_t patch_size;   /* 32  */
+    int32_t hidden;       /* 768 */
+    int32_t mlp;          /* 3072 */
+    int32_t layers;       /* 12 */
+    int32_t heads;        /* 12 */
+    int32_t proj_dim;     /* 512 */
+    float ln_eps;         /* 1e-5 */
+} vq_vit_config;
+
+/* weights: n_weights host fp32 tensors in the order of
+ * video-quierer_amd/weights.py:weight_shapes() (HF state_dict names; 5 + 16*layers + 3).
+ * Replaces CLIPModel.from_pretrained + .to(device) (feature_extractor.py:76-81).
+ * max_batch: frames per device pass (workspace is sized for it). */
+int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int n_weights,
+                      int max_batch, vq_encoder** out);
+int vq_encoder_destroy(vq_encoder* enc);
+
+/* extract_batch (feature_extractor.py:137-177) for uint8 frames already at
+ * image_size x image_size: frames [n][S][S][3] -> out [n][proj_dim] fp32,
+ * L2-normalised.  swap_rb=1 is the ndarray path (BGR->RGB, :111-112), 0 the PIL
+ * path.  Any n >= 0 (processed in max_batch slices); synchronous. */
+int vq_encoder_encode_u8(vq_encoder* enc, const uint8_t* frames, int n, int swap_rb, float* out);
+
+/* Same, device-resident input/output, n <= max_batch, asynchronous.
+ * d_out_f16 (optional, may be NULL) receives an fp16 copy of the embeddings. */
+int vq_encoder_encode_u8_device(vq_encoder* enc, const void* d_frames, int n, int swap_rb,
+                                void* d_out_f32, void* d_out_f16);
+int vq_encoder_synchronize(vq_encoder* enc);
+/* Run this handle's kernels on a caller-owned HIP stream (e.g. torch's current
+ * stream, so RCCL collectives issued by torch order after the encode without a
+ * host sync).  NULL restores the handle's own stream. */
+int vq_encoder_set_stream(vq_encoder* enc, void* hip_stream);
+int vq_encoder_output_dim(vq_encoder* enc, int* dim);
+
+/* Per-kernel-class device timing with HIP events on the encoder's stream
+ * (bench.py roofline leg).  Between begin/end every launch is bracketed by
+ * events; end() reports total ms and launch count per class. */
+#define VQ_ENC_NCLASS 10
+int vq_encoder_profile_begin(vq_encoder* enc);
+int vq_encoder_profile_end(vq_encoder* enc, float* ms /*[VQ_ENC_NCLASS]*/, int* launches /*[VQ_ENC_NCLASS]*/);
+const char* vq_encoder_profile_class_name(int cls);
+
+/* Test hooks: run only the first `layers` transformer blocks (<0: all), and copy
+ * an internal activation to the host as fp32: "x" [n*T][hidden] residual stream,
+ * "h" LN output, "qkv", "att", "mlp" (bf16 widened). */
+int vq_encoder_debug_set_layers(vq_encoder* enc, int layers);
+int vq_encoder_debug_read(vq_encoder* enc, const char* name, int rows, float* out);
+
+/* C[M][N] = A[M][K] * W[N][K]^T through the production MFMA mainloop (bf16 or
+ * fp16 inputs rounded from the given fp32, fp32 accumulate) — unit-test hook. */
+int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int use_f16, float* C);
+
+/* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
+typedef struct vq_index vq_index;
+
+/* HNSWIndex.__init__ (hnsw.py:25-57).  The graph parameters (M, ef_*) have no
+ * device-side meaning: the index is an exact scan. */
+int vq_index_create(int dim, vq_index** out);
+int vq_index_destroy(vq_index* idx);
+
+/* add / add_batch (hnsw.py:150-236): appends n rows.  normalize=1 divides each
+ * row by its L2 norm on the device (fixed-order fp64 chain, see oracle/knn_oracle.c);
+ * normalize=0 stores the rows as given (the Python wrapper normalises with numpy
+ * exactly like the reference, hnsw.py:157, and passes 0). */
+int vq_index_add(vq_index* idx, const float* rows, int64_t n, int normalize);
+int vq_index_add_device(vq_index* idx, const void* d_rows_f32, int64_t n, int normalize);
+int vq_index_size(vq_index* idx, int64_t* n);
+int vq_index_clear(vq_index* idx);
+
+/* search / search_batch (hnsw.py:238-300, 488-528) as an exact scan:
+ *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row).
+ * queries [nq][dim] must already be L2-normalised (the wrapper does query /
+ * ||query|| with numpy, hnsw.py:250).  ids/dist are [nq][k]; unused slots
+ * (k > size) are id -1 / dist +inf.  mode: 0 auto, 1 exact fp32-master scan,
+ * 2 fp16 MFMA scan + exact re-score. */
+int vq_index_search(vq_index* idx, const float* queries, int nq, int k, int mode,
+                    int32_t* ids, float* dist);
+int vq_index_search_device(vq_index* idx, const void* d_queries_f32, int nq, int k, int mode,
+                           void* d_ids_i32, void* d_dist_f32);
+int vq_index_synchronize(vq_index* idx);
+int vq_index_set_stream(vq_index* idx, void* hip_stream);
+
+/* save / load support (hnsw.py:306-380): the stored (normalised) rows. */
+int vq_index_export(vq_index* idx, float* rows /*[size][dim]*/);
+
+/* Device timing of the scan kernels between begin/end (bench.py roofline leg). */
+#define VQ_IDX_NCLASS 6
+int vq_index_profile_begin(vq_index* idx);
+int vq_index_profile_end(vq_index* idx, float* ms /*[VQ_IDX_NCLASS]*/, int* launches /*[VQ_IDX_NCLASS]*/);
+const char* vq_index_profile_class_name(int cls);
+/* counters of the last fp16-scan search: [0] queries verified exact by the
+ * margin test, [1] queries that needed block rescans, [2] queries sent to the
+ * full exact scan */
+int vq_index_last_search_stats(vq_index* idx, int64_t* stats /*[3]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ_AMD_H */

@@ -53,7 +53,7 @@ def _ln(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.
 
 
 def vit_forward(pixel: torch.Tensor, W: Dict[str, torch.Tensor], *, patch: int, heads: int,
-                layers: int, eps: float = 1e-5) -> torch.Tensor:
+                layers: int, eps: float = 1e-5, return_hidden: bool = False) -> torch.Tensor:
     """fp32 [n,3,H,W] → fp32 [n,proj_dim] (un-normalised image features).
 
     tf:202-218 embeddings, :641-642 pre-LN, :362-383 encoder layer (pre-LN
@@ -93,6 +93,8 @@ def vit_forward(pixel: torch.Tensor, W: Dict[str, torch.Tensor], *, patch: int, 
         h = h @ W[pre + "mlp.fc1.weight"].t() + W[pre + "mlp.fc1.bias"]
         h = h * torch.sigmoid(1.702 * h)
         x = x + (h @ W[pre + "mlp.fc2.weight"].t() + W[pre + "mlp.fc2.bias"])
+    if return_hidden:            # residual stream after `layers` blocks (layer-wise parity tests)
+        return x
     pooled = _ln(x[:, 0, :], W["vision_model.post_layernorm.weight"],
                  W["vision_model.post_layernorm.bias"], eps)
     return pooled @ W["visual_projection.weight"].t()

@@ -1,0 +1,279 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracles and the
+golden vectors.  Run on the MI355X box with `-m gpu`."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import INDEX_SEED, synth_frames
+from oracle import clip_vit_oracle, knn_oracle
+
+pytestmark = pytest.mark.gpu
+
+# tolerance of the north star: cosine scores within 1e-3 (fp32)
+COS_TOL = 1e-3
+
+
+# ------------------------------------------------------------------ GEMM mainloop
+def test_gemm_mfma_integer_exact(gpu_lib):
+    from video_quierer_amd.encoder import debug_gemm
+    rng = np.random.default_rng(0)
+    m, n, k = 256, 256, 192
+    a = np.zeros((m, k), np.float32)
+    a[np.arange(m), np.arange(m) % k] = 1.0                  # row i picks column i % k  ("A = I" check)
+    w = rng.integers(-8, 9, (n, k)).astype(np.float32)       # asymmetric W catches a transposed C write
+    c = debug_gemm(a, w)
+    assert np.array_equal(c, a @ w.T)
+    a = rng.integers(-4, 5, (m, k)).astype(np.float32)
+    for f16 in (False, True):
+        assert np.array_equal(debug_gemm(a, w, use_f16=f16), a @ w.T)   # small ints: exact in bf16/fp16/fp32-acc
+
+
+def test_gemm_mfma_random(gpu_lib):
+    from video_quierer_amd.encoder import debug_gemm
+    rng = np.random.default_rng(1)
+    m, n, k = 384, 128, 3072
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    ab = torch.from_numpy(a).bfloat16().float().numpy()
+    wb = torch.from_numpy(w).bfloat16().float().numpy()
+    ref = ab.astype(np.float64) @ wb.astype(np.float64).T
+    c = debug_gemm(a, w)
+    assert np.abs(c - ref).max() <= 2e-3 * np.sqrt(k)        # fp32 accumulation of exact bf16 products
+
+
+# ------------------------------------------------------------------ encoder
+@pytest.fixture(scope="module")
+def encoder(gpu_lib, b32_weights):
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    enc = VitEncoder(VIT_B_32, b32_weights, max_batch=64)
+    yield enc
+    enc.close()
+
+
+def _oracle_hidden(frames, weights, layers):
+    W = {k: torch.from_numpy(v) for k, v in weights.items()}
+    with torch.no_grad():
+        px = clip_vit_oracle.preprocess_u8(frames, True)
+        return clip_vit_oracle.vit_forward(px, W, patch=32, heads=12, layers=layers, return_hidden=True).numpy()
+
+
+@pytest.mark.parametrize("layers", [0, 1, 12])
+def test_encoder_residual_stream_layerwise(encoder, b32_weights, layers):
+    frames = synth_frames(4, seed=99)
+    encoder.debug_set_layers(layers)
+    try:
+        encoder.encode(frames)
+        x = encoder.debug_read("x", 4 * 50).reshape(4, 50, 768)
+    finally:
+        encoder.debug_set_layers(-1)
+    ref = _oracle_hidden(frames, b32_weights, layers)
+    rel = np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    assert rel < (2e-3 if layers == 0 else 1.5e-2), f"residual stream after {layers} layers: rel err {rel}"
+
+
+def test_encoder_matches_golden_embeddings(encoder, golden_encoder):
+    emb = encoder.encode(synth_frames(64))
+    assert emb.shape == (64, 512) and emb.dtype == np.float32
+    assert np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    cos = np.sum(emb * golden_encoder["embeddings"], axis=1)
+    assert cos.min() >= 1.0 - COS_TOL, f"min cosine vs transformers fp32 = {cos.min()}"
+    # cosine scores against arbitrary index rows stay within the tolerance too
+    rows = knn_oracle.normalize_rows(np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32))
+    assert np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T).max() <= COS_TOL
+
+
+def test_encoder_batch_shapes_and_paths(encoder, b32_weights):
+    frames = synth_frames(70, seed=3)                 # > max_batch=64: two device passes, ragged tail of 6
+    full = encoder.encode(frames)
+    assert full.shape == (70, 512)
+    one = encoder.encode(frames[17:18])
+    assert np.abs(one[0] - full[17]).max() <= 2e-3    # batch composition only changes GEMM padding rows
+    again = encoder.encode(frames)
+    assert np.array_equal(full, again)                # deterministic
+    rgb = encoder.encode(np.ascontiguousarray(frames[:5, ..., ::-1]), swap_rb=False)   # PIL path
+    assert np.array_equal(rgb, full[:5])
+    assert encoder.encode(frames[:0]).shape == (0, 512)
+    ref = clip_vit_oracle.encode_frames(frames[:8], b32_weights, batch_size=8)
+    assert np.sum(full[:8] * ref, axis=1).min() >= 1.0 - COS_TOL
+    with pytest.raises(ValueError):
+        encoder.encode(np.zeros((1, 200, 224, 3), np.uint8))
+
+
+def test_feature_extractor_api(gpu_lib, b32_weights):
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=32, device_batch=64)
+    assert fx.output_dim == 512 and fx.batch_size == 32 and str(fx.device).startswith("cuda")
+    assert fx.get_stats() == {"total_processed": 0, "avg_extraction_time": 0, "throughput": 0}
+    assert fx.extract_batch([]).shape == (0,)
+    frames = synth_frames(70, seed=21)
+    fd = [{"frame": f, "timestamp": i / 30.0, "frame_number": i} for i, f in enumerate(frames)]
+    out = fx.extract_from_video_frames(fd)
+    assert len(out) == 70 and [o["frame_number"] for o in out] == list(range(70))
+    assert "features" not in fd[0] and out[0]["features"].shape == (512,) and out[0]["features"].dtype == np.float32
+    assert all(o["feature_extraction_time"] >= 0 for o in out)
+    ref = clip_vit_oracle.extract_from_video_frames(fd[:6], b32_weights, batch_size=32)
+    for o, r in zip(out[:6], ref):
+        assert float(np.dot(o["features"], r["features"])) >= 1.0 - COS_TOL
+    single = fx.extract_features(frames[3])
+    assert float(np.dot(single, out[3]["features"])) >= 1.0 - 1e-4
+    from PIL import Image
+    pil = fx.extract_features(Image.fromarray(np.ascontiguousarray(frames[3][..., ::-1])))   # RGB PIL == BGR ndarray
+    assert np.allclose(pil, single, atol=2e-3)
+    st = fx.get_stats()
+    assert set(st) == {"total_processed", "avg_extraction_time", "throughput_images_per_sec", "device",
+                       "model_name", "output_dimension"} and st["total_processed"] == 72
+    with pytest.raises(NotImplementedError):
+        fx.extract_text_features("a cat")
+    with pytest.raises(RuntimeError):
+        FeatureExtractor(model_name="seed:1234", device="cpu")
+    fx.thread_pool.shutdown()
+
+
+# ------------------------------------------------------------------ index
+def _mk_index(vecs, ids=None):
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    idx = OptimizedHNSWIndex(dimension=vecs.shape[1], M=16, ef_construction=200, ef_search=50, max_M=16)
+    idx.add_batch(list(vecs), list(range(len(vecs))) if ids is None else ids)
+    return idx
+
+
+def test_index_config1_matches_reference_and_oracle(gpu_lib, golden_knn, golden_encoder):
+    vecs = np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32)
+    idx = _mk_index(vecs)
+    assert idx.size() == 1000
+    assert np.array_equal(idx._export(), golden_knn["stored"])          # stored rows == reference .data
+    qs = golden_encoder["embeddings"]
+    unit_q = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    for k in (5, 10):
+        res = idx.search_batch(list(qs), k)
+        ids = np.array([[r["id"] for r in rr] for rr in res], dtype=np.int32)
+        d = np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32)
+        sc = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32)
+        oid, od = knn_oracle.topk(golden_knn["stored"], unit_q, k)
+        assert np.array_equal(ids, oid) and np.array_equal(d, od)       # bit-exact vs the oracle
+        assert np.array_equal(ids, golden_knn[f"ids_ef1000_k{k}"])      # identical lists vs the exhaustive reference
+        assert np.abs(d - golden_knn[f"dist_ef1000_k{k}"]).max() <= 2e-7
+        assert np.abs(sc - golden_knn[f"score_ef1000_k{k}"]).max() <= 2e-7
+        one = idx.search(qs[5], k)
+        assert [r["id"] for r in one] == list(ids[5]) and type(one[0]["distance"]) is np.float32
+    st = idx.get_stats()
+    assert st["element_count"] == 1000 and st["total_searches"] == 64 * 2 + 2 and st["M"] == 16 and st["ef_search"] == 50
+    idx.thread_pool.shutdown()
+
+
+def test_index_edge_cases(gpu_lib, tmp_path):
+    from video_quierer_amd.indexes.hnsw import HNSWIndex, OptimizedHNSWIndex
+    rng = np.random.default_rng(5)
+    empty = HNSWIndex(dimension=64)
+    assert empty.search(rng.standard_normal(64).astype(np.float32), 3) == [] and empty.size() == 0
+    assert empty.search_batch([rng.standard_normal(64).astype(np.float32)] * 2, 3) == [[], []]
+
+    vecs = rng.standard_normal((37, 64)).astype(np.float32)          # ragged: not a multiple of any tile
+    idx = _mk_index(vecs)
+    q = rng.standard_normal(64).astype(np.float32)
+    res = idx.search(q, 50)                                           # k > n → n results
+    assert len(res) == 37 and sorted(r["id"] for r in res) == list(range(37))
+    d = [r["distance"] for r in res]
+    assert d == sorted(d)
+
+    # exact duplicates: ties broken by the smaller id — numeric ids and (lexicographic) string ids
+    dup = np.concatenate([vecs, vecs[:4]])
+    idx2 = _mk_index(dup)
+    r2 = idx2.search(vecs[2], 2)
+    assert [r["id"] for r in r2] == [2, 39] and r2[0]["distance"] == r2[1]["distance"]
+    names = [f"v_{i}" for i in range(len(dup))]
+    names[2], names[39] = "z_2", "a_39"                              # the LATER row carries the smaller id
+    idx3 = _mk_index(dup, ids=names)
+    r3 = idx3.search(vecs[2], 2)
+    assert [r["id"] for r in r3] == ["a_39", "z_2"] and r3[0]["distance"] == r3[1]["distance"]
+    r3b = idx3.search(vecs[2], 1)                                     # tie group cut at rank k: still the smaller id
+    assert r3b[0]["id"] == "a_39"
+    assert idx3.search(vecs[3], 1)[0]["id"] == "v_3"                  # "v_3" < "v_40"
+
+    # incremental adds, re-add of an existing id replaces its vector
+    idx.add(vecs[0] * 3.0, 100)
+    assert idx.size() == 38 and idx.search(vecs[0], 2)[1]["id"] in (0, 100)
+    idx.add(vecs[5], 1)                                               # id 1 now holds vecs[5]
+    top = idx.search(vecs[5], 2)
+    assert {top[0]["id"], top[1]["id"]} == {1, 5}
+
+    # save / load round trip (pickle + sha256 sidecar, reference keys)
+    path = os.path.join(tmp_path, "sub", "index.pkl")
+    idx3.save(path)
+    with open(path, "rb") as f:
+        blob = pickle.load(f)
+    for key in ("dimension", "M", "max_M", "ef_construction", "ef_search", "level_generation_factor", "data",
+                "levels", "graph", "entry_point", "element_count"):
+        assert key in blob
+    fresh = OptimizedHNSWIndex(dimension=64)
+    fresh.load(path)
+    assert fresh.size() == idx3.size()
+    assert [r["id"] for r in fresh.search(vecs[2], 2)] == [r["id"] for r in r3]
+    with open(path, "ab") as f:
+        f.write(b"x")
+    with pytest.raises(ValueError):
+        OptimizedHNSWIndex(dimension=64).load(path)
+    with pytest.raises(ValueError):
+        idx.search(np.zeros(32, np.float32), 1)                       # wrong dimension
+
+
+def test_index_device_normalise_matches_oracle(gpu_lib):
+    from video_quierer_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(8)
+    raw = (rng.standard_normal((300, 512)) * 3).astype(np.float32)
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.vq_index_create(512, ctypes.byref(h)))
+    _lib.check(lib.vq_index_add(h, _lib.fptr(raw), 300, 1))            # normalize on the device
+    out = np.empty_like(raw)
+    _lib.check(lib.vq_index_export(h, _lib.fptr(out)))
+    lib.vq_index_destroy(h)
+    assert np.array_equal(out, knn_oracle.normalize_rows(raw))         # same fixed-order definition, bit-exact
+
+
+def test_index_larger_ragged_vs_oracle(gpu_lib):
+    rng = np.random.default_rng(12)
+    vecs = rng.standard_normal((4001, 512)).astype(np.float32)        # config-4 sized, ragged
+    idx = _mk_index(vecs)
+    qs = rng.standard_normal((130, 512)).astype(np.float32)
+    res = idx.search_batch(list(qs), 10)
+    stored = np.stack([v / np.linalg.norm(v) for v in vecs]).astype(np.float32)
+    uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    oid, od = knn_oracle.topk(stored, uq, 10)
+    assert np.array_equal(np.array([[r["id"] for r in rr] for rr in res]), oid)
+    assert np.array_equal(np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32), od)
+
+
+# ------------------------------------------------------------------ end to end (config 1)
+def test_config1_end_to_end(gpu_lib, encoder, golden_knn, golden_encoder):
+    emb = encoder.encode(synth_frames(64))
+    vecs = np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32)
+    idx = _mk_index(vecs)
+    res = idx.search_batch(list(emb), 5)
+    ids = np.array([[r["id"] for r in rr] for rr in res], dtype=np.int32)
+    sc = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32)
+    # exactness of the search on the GPU embeddings themselves
+    uq = np.stack([q / np.linalg.norm(q) for q in emb]).astype(np.float32)
+    oid, od = knn_oracle.topk(golden_knn["stored"], uq, 5)
+    assert np.array_equal(ids, oid)
+    # against the all-reference pipeline (transformers fp32 embeddings + exhaustive hnsw.py):
+    # scores within 1e-3; id lists identical wherever the reference's own gaps exceed the tolerance
+    ref_ids, ref_sc = golden_knn["ids_ef1000_k5"], golden_knn["score_ef1000_k5"]
+    ref_d10 = golden_knn["dist_ef1000_k10"]
+    same = 0
+    for i in range(64):
+        gaps = np.diff(ref_d10[i][:6])
+        if gaps.min() > 2 * COS_TOL:
+            assert list(ids[i]) == list(ref_ids[i])
+            assert np.abs(sc[i] - ref_sc[i]).max() <= COS_TOL
+            same += 1
+        else:
+            assert set(ids[i]) <= set(golden_knn["ids_ef1000_k10"][i]) | set(ids[i])
+    recall = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(ids, ref_ids)])
+    print(f"config1: {same}/64 queries gap-checked identical; recall@5 vs reference pipeline {recall:.4f}")
+    assert recall >= 0.95

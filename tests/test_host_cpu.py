@@ -1,0 +1,94 @@
+"""CPU (`-m "not gpu"`): the C-ABI library loads and exports every symbol
+include/vq_amd.h declares; host-side logic that needs no device; loud failure
+without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _build()
+    from video_quierer_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "vq_amd.h")).read()
+    declared = set(re.findall(r"\b(vq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes found in include/vq_amd.h"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in vq_amd.h but not exported by libvq_amd.so"
+    assert lib.vq_version().decode().startswith("vq_amd")
+    assert lib.vq_encoder_profile_class_name(7).decode() == "gemm_fc1_quickgelu"
+    assert lib.vq_index_profile_class_name(2).decode() == "exact_dist_f64chain"
+
+
+def test_no_cpu_fallback_when_device_missing():
+    """On a box without a GPU every product entry point must raise, never compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _build()
+    from video_quierer_amd import _lib
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    with pytest.raises(_lib.VqError):
+        _lib.init(0)
+    with pytest.raises(_lib.VqError):
+        OptimizedHNSWIndex(dimension=512)
+    with pytest.raises((_lib.VqError, RuntimeError)):
+        FeatureExtractor(model_name="seed:1")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "video-quierer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{fn} imports the oracle"
+                assert "knn_oracle" not in text.replace("oracle/knn_oracle.c", ""), f"{fn} references the oracle library"
+
+
+def test_weight_catalogue_and_seeded_weights():
+    from video_quierer_amd.weights import VIT_B_32, VIT_L_14_336, resolve_model, seeded_weights, weight_shapes
+    shapes = weight_shapes(VIT_B_32)
+    assert len(shapes) == 5 + 16 * 12 + 3
+    assert sum(int(np.prod(s)) for _, s in shapes) == 87_849_216
+    assert VIT_B_32.tokens == 50 and VIT_B_32.macs_per_frame() == 4_408_811_520
+    assert VIT_L_14_336.tokens == 577
+    a, b = seeded_weights(VIT_B_32, 7), seeded_weights(VIT_B_32, 7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert not np.array_equal(a["visual_projection.weight"], seeded_weights(VIT_B_32, 8)["visual_projection.weight"])
+    cfg, w = resolve_model("seed:7")
+    assert cfg == VIT_B_32 and np.array_equal(w["visual_projection.weight"], a["visual_projection.weight"])
+    with pytest.raises(FileNotFoundError):
+        resolve_model("openai/clip-vit-base-patch32")                   # never fetched
+
+
+def test_dropin_import_paths():
+    import sys
+    import video_quierer_amd
+    video_quierer_amd.install_dropin()
+    from core.feature_extractor import BatchProcessor, CachedFeatureExtractor, FeatureExtractor   # noqa: F401
+    from indexes.hnsw import HNSWIndex, OptimizedHNSWIndex                                         # noqa: F401
+    assert sys.modules["core.feature_extractor"].__name__ == "video_quierer_amd.core.feature_extractor"
+    import inspect
+    sig = inspect.signature(FeatureExtractor.__init__)
+    assert list(sig.parameters)[1:6] == ["model_name", "device", "batch_size", "num_threads", "cache_model"]
+    assert sig.parameters["batch_size"].default == 32 and sig.parameters["device"].default == "auto"
+    sig = inspect.signature(HNSWIndex.__init__)
+    assert list(sig.parameters)[1:8] == ["dimension", "M", "ef_construction", "ef_search", "max_M",
+                                         "level_generation_factor", "num_threads"]
+    for name in ("add", "add_batch", "search", "search_batch", "size", "save", "load", "get_stats"):
+        assert callable(getattr(OptimizedHNSWIndex, name))
+    for name in ("extract_features", "extract_batch", "extract_from_video_frames", "extract_batch_async",
+                 "extract_text_features", "get_stats"):
+        assert callable(getattr(FeatureExtractor, name))

@@ -1,0 +1,103 @@
+"""CPU: the oracles against the golden vectors captured from the real
+transformers CLIP model and the real reference hnsw.py (tests/golden/make_golden.py)."""
+import hashlib
+import random
+
+import numpy as np
+
+from conftest import INDEX_SEED, synth_frames
+from oracle import clip_vit_oracle, hnsw_oracle, knn_oracle
+
+
+def test_synthetic_inputs_match_capture(golden_encoder, b32_weights):
+    frames = synth_frames(64)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(golden_encoder["frames_sha256"])
+    h = hashlib.sha256()
+    for k in sorted(b32_weights):
+        h.update(b32_weights[k].tobytes())
+    assert h.hexdigest() == str(golden_encoder["weights_sha256"])
+
+
+def test_encoder_oracle_matches_transformers(golden_encoder, b32_weights):
+    emb = clip_vit_oracle.encode_frames(synth_frames(64), b32_weights, batch_size=32)
+    assert emb.dtype == np.float32 and emb.shape == (64, 512)
+    assert np.abs(emb - golden_encoder["embeddings"]).max() <= 1e-5
+    assert np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-6)
+
+
+def test_encoder_oracle_edge_cases(b32_weights):
+    assert clip_vit_oracle.encode_frames(np.zeros((0, 224, 224, 3), np.uint8), b32_weights).shape == (0,)
+    f = synth_frames(3, seed=5)
+    # batch slicing does not change results; PIL path (no channel swap) == pre-swapped ndarray path
+    a = clip_vit_oracle.encode_frames(f, b32_weights, batch_size=2)
+    b = clip_vit_oracle.encode_frames(f, b32_weights, batch_size=3)
+    assert np.abs(a - b).max() < 1e-6
+    c = clip_vit_oracle.encode_frames(f[..., ::-1], b32_weights, swap_rb=False)
+    assert np.abs(a - c).max() < 1e-6
+
+
+def test_extract_from_video_frames_shape(b32_weights):
+    frames = synth_frames(5, seed=11)
+    fd = [{"frame": f, "timestamp": i * 0.5, "frame_number": i} for i, f in enumerate(frames)]
+    out = clip_vit_oracle.extract_from_video_frames(fd, b32_weights, batch_size=2)
+    assert [o["frame_number"] for o in out] == list(range(5))
+    assert all(o["features"].shape == (512,) and "feature_extraction_time" in o for o in out)
+    assert "features" not in fd[0]          # copies, not in-place
+
+
+def _build_hnsw(n=1000):
+    vecs = np.random.default_rng(INDEX_SEED).standard_normal((n, 512)).astype(np.float32)
+    random.seed(0)
+    h = hnsw_oracle.HnswOracle(512)
+    h.add_batch(list(vecs), list(range(n)))
+    return h
+
+
+def test_hnsw_restatement_builds_the_reference_graph(golden_knn):
+    h = _build_hnsw()
+    assert np.array_equal(np.array(h.level, dtype=np.int32), golden_knn["levels"])
+    assert h.ids[h.entry] == int(golden_knn["entry_point"])
+    assert np.array_equal(np.stack(h.vec), golden_knn["stored"])
+    edges = sorted((lv, a, b) for a in range(len(h.ids)) for lv, s in enumerate(h.adj[a]) for b in s)
+    assert np.array_equal(np.array(edges, dtype=np.int32), golden_knn["edges"])
+
+
+def test_hnsw_restatement_search_lists(golden_knn, golden_encoder):
+    h = _build_hnsw()
+    for ef in (50, 1000):
+        h.ef_search = ef
+        for k in (5, 10):
+            res = [h.search(q, k) for q in golden_encoder["embeddings"]]
+            ids = np.array([[r["id"] for r in rr] for rr in res], dtype=np.int32)
+            d = np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32)
+            sc = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32)
+            assert np.array_equal(ids, golden_knn[f"ids_ef{ef}_k{k}"])
+            assert np.array_equal(d, golden_knn[f"dist_ef{ef}_k{k}"])
+            assert np.array_equal(sc, golden_knn[f"score_ef{ef}_k{k}"])
+    assert type(res[0][0]["distance"]) is np.float32
+
+
+def test_exact_oracle_equals_exhaustive_reference(golden_knn, golden_encoder):
+    q = np.stack([e / np.linalg.norm(e) for e in golden_encoder["embeddings"]]).astype(np.float32)
+    for k in (5, 10):
+        ids, d = knn_oracle.topk(golden_knn["stored"], q, k)
+        assert np.array_equal(ids, golden_knn[f"ids_ef1000_k{k}"])            # identical id lists
+        assert np.abs(d - golden_knn[f"dist_ef1000_k{k}"]).max() <= 2e-7      # fixed-order dot vs BLAS order
+    # the reference at its default ef_search=50 is approximate: report its recall vs exact
+    ids10, _ = knn_oracle.topk(golden_knn["stored"], q, 10)
+    rec = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(golden_knn["ids_ef50_k10"], ids10)])
+    assert 0.5 < rec < 1.0
+
+
+def test_exact_oracle_edge_cases():
+    rng = np.random.default_rng(3)
+    x = knn_oracle.normalize_rows(rng.standard_normal((7, 16)).astype(np.float32))
+    assert np.allclose(np.linalg.norm(x, axis=1), 1, atol=1e-6)
+    ids, d = knn_oracle.topk(x, x[:2], 10)                  # k > n: padded with -1 / +inf
+    assert (ids[:, 7:] == -1).all() and np.isinf(d[:, 7:]).all()
+    assert ids[0, 0] == 0 and ids[1, 0] == 1
+    dup = np.concatenate([x, x[:3]])                        # exact duplicates: ties broken by smaller row
+    ids, d = knn_oracle.topk(dup, x[:1], 2)
+    assert list(ids[0]) == [0, 7] and d[0, 0] == d[0, 1]
+    bf = hnsw_oracle.brute_force(dup, list(range(10)), x[0], 2)
+    assert [r["id"] for r in bf] == [0, 7]

@@ -1,0 +1,125 @@
+"""ctypes binding of libvq_amd.so (include/vq_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950
+device is visible, the calls below raise.  ``load()`` only needs the file (so
+the symbol-export test can run on a box without a GPU); ``init()`` needs the
+device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvq_amd.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+ENC_NCLASS = 10
+IDX_NCLASS = 6
+
+
+class VqError(RuntimeError):
+    """A libvq_amd call failed (message from vq_last_error)."""
+
+
+class VitConfigC(ctypes.Structure):
+    _fields_ = [("image_size", c_int32), ("patch_size", c_int32), ("hidden", c_int32), ("mlp", c_int32),
+                ("layers", c_int32), ("heads", c_int32), ("proj_dim", c_int32), ("ln_eps", c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/vq_amd.h declares
+SIGNATURES = {
+    "vq_init": (c_int, [c_int]),
+    "vq_device_count": (c_int, [POINTER(c_int)]),
+    "vq_last_error": (c_char_p, []),
+    "vq_version": (c_char_p, []),
+    "vq_encoder_create": (c_int, [POINTER(VitConfigC), POINTER(POINTER(c_float)), c_int, c_int, POINTER(c_void_p)]),
+    "vq_encoder_destroy": (c_int, [c_void_p]),
+    "vq_encoder_encode_u8": (c_int, [c_void_p, POINTER(c_uint8), c_int, c_int, POINTER(c_float)]),
+    "vq_encoder_encode_u8_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vq_encoder_synchronize": (c_int, [c_void_p]),
+    "vq_encoder_set_stream": (c_int, [c_void_p, c_void_p]),
+    "vq_encoder_output_dim": (c_int, [c_void_p, POINTER(c_int)]),
+    "vq_encoder_profile_begin": (c_int, [c_void_p]),
+    "vq_encoder_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
+    "vq_encoder_profile_class_name": (c_char_p, [c_int]),
+    "vq_encoder_debug_set_layers": (c_int, [c_void_p, c_int]),
+    "vq_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_float)]),
+    "vq_debug_gemm": (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, POINTER(c_float)]),
+    "vq_index_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "vq_index_destroy": (c_int, [c_void_p]),
+    "vq_index_add": (c_int, [c_void_p, POINTER(c_float), c_int64, c_int]),
+    "vq_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "vq_index_size": (c_int, [c_void_p, POINTER(c_int64)]),
+    "vq_index_clear": (c_int, [c_void_p]),
+    "vq_index_search": (c_int, [c_void_p, POINTER(c_float), c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
+    "vq_index_search_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vq_index_synchronize": (c_int, [c_void_p]),
+    "vq_index_set_stream": (c_int, [c_void_p, c_void_p]),
+    "vq_index_export": (c_int, [c_void_p, POINTER(c_float)]),
+    "vq_index_profile_begin": (c_int, [c_void_p]),
+    "vq_index_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
+    "vq_index_profile_class_name": (c_char_p, [c_int]),
+    "vq_index_last_search_stats": (c_int, [c_void_p, POINTER(c_int64)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+_device = None
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into lib/libvq_amd.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise VqError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for this path)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().vq_last_error()
+        text = msg.decode("utf-8", "replace") if msg else "unknown error"
+        if rc == -1:
+            raise ValueError(f"libvq_amd: {text}")
+        raise VqError(f"libvq_amd (code {rc}): {text}")
+
+
+def init(device: int | None = None) -> int:
+    """Bind this process to a GPU (default: $LOCAL_RANK or 0).  Raises without a gfx950 device."""
+    global _device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _device is None else _device
+    if _device != device:
+        check(lib.vq_init(int(device)))
+        _device = device
+    return _device
+
+
+def device_count() -> int:
+    n = c_int(0)
+    check(load().vq_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def fptr(a):
+    return a.ctypes.data_as(POINTER(c_float))

@@ -1,0 +1,381 @@
+// Device kernels of the CLIP ViT image-encoder forward pass other than the GEMM
+// mainloop: GEMM epilogues, patch extraction, LayerNorm, single-tile attention,
+// pooling head.  gfx950 only.  Row references are to SURVEY.md §8a (E-rows).
+#pragma once
+#include "vq_common.h"
+
+namespace vq {
+
+// ============================ GEMM epilogues =================================
+// Each is called with (m, n, v) where v = C[m][n..n+3] (fp32 accumulators).
+
+__device__ __forceinline__ uint2 pack4_bf16(f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(uint2, b);
+}
+
+// y = acc + bias  -> bf16                      (E6: fused q|k|v projection)
+struct EpiBiasBf16 {
+    uint16_t* out; int ldo; const float* bias;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const float4 b = *(const float4*)(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_bf16(v);
+    }
+};
+
+// y = quick_gelu(acc + bias) -> bf16           (E7: fc1; x*sigmoid(1.702x))
+struct EpiBiasQuickGeluBf16 {
+    uint16_t* out; int ldo; const float* bias;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const float4 b = *(const float4*)(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_bf16(v);
+    }
+};
+
+// x += acc + bias   (fp32 residual stream)      (E5: out_proj / fc2 + residual)
+struct EpiBiasResidualF32 {
+    float* x; int ldx; const float* bias;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const float4 b = *(const float4*)(bias + n);
+        float4* p = (float4*)(x + (size_t)m * ldx + n);
+        float4 r = *p;
+        r.x += v[0] + b.x; r.y += v[1] + b.y; r.z += v[2] + b.z; r.w += v[3] + b.w;
+        *p = r;
+    }
+};
+
+// Patch-embedding GEMM: GEMM row m = (image b, patch p) -> token row b*T + 1 + p;
+// x = acc + folded_bias + position_embedding[1+p]          (E3)
+struct EpiPatchEmbedF32 {
+    float* x; int hidden; const float* bias; const float* pos; int patches; int tokens; int m_valid;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        if (m >= m_valid) return;
+        const int b = m / patches, p = m - b * patches;
+        const float4 bb = *(const float4*)(bias + n);
+        const float4 pp = *(const float4*)(pos + (size_t)(1 + p) * hidden + n);
+        float4 r = {v[0] + bb.x + pp.x, v[1] + bb.y + pp.y, v[2] + bb.z + pp.z, v[3] + bb.w + pp.w};
+        *(float4*)(x + ((size_t)b * tokens + 1 + p) * hidden + n) = r;
+    }
+};
+
+// ============================ patch extraction ===============================
+// uint8 frames [n][S][S][3] -> bf16 GEMM operand [n*P][3*ps*ps], K ordered
+// (c, ky, kx) like Conv2d's weight [hidden,3,ps,ps] (E3).  The value stored is
+// (pixel - 128): exact in bf16; ToTensor's /255 and Normalize's (x-mean)/std
+// (E1) are folded into the patch weights and a per-output bias on the host.
+// swap_rb=1 reverses the channel axis (cv2.COLOR_BGR2RGB for ndarray input, E1).
+// One thread handles 8 consecutive pixels of one image row (24 contiguous bytes)
+// and writes three 16-byte runs, one per channel plane.  Requires ps % 8 == 0.
+__global__ __launch_bounds__(256)
+void patchify_u8_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ out,
+                        int n, int S, int ps, int swap_rb) {
+    const int runs_per_row = S / 8;
+    const int64_t total = (int64_t)n * S * runs_per_row;
+    const int grid = S / ps;
+    const int Kp = 3 * ps * ps;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int xr = (int)(t % runs_per_row);
+        const int64_t t2 = t / runs_per_row;
+        const int y = (int)(t2 % S);
+        const int b = (int)(t2 / S);
+        const uint8_t* src = frames + (((int64_t)b * S + y) * S + xr * 8) * 3;   // 8-B aligned
+        const uint2 r0 = *(const uint2*)(src), r1 = *(const uint2*)(src + 8), r2 = *(const uint2*)(src + 16);
+        const uint32_t w[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+        const int gy = y / ps, ky = y - gy * ps;
+        const int x0 = xr * 8, gx = x0 / ps, kx = x0 - gx * ps;
+        uint16_t* dst = out + ((size_t)b * grid * grid + gy * grid + gx) * Kp + ky * ps + kx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = swap_rb ? 2 - c : c;                 // source channel for model channel c
+            uint16_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int byte = i * 3 + cs;
+                const int px = (w[byte >> 2] >> ((byte & 3) * 8)) & 0xff;
+                v[i] = f32_to_bf16_rne((float)(px - 128));
+            }
+            uint4 o = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                       (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+            *(uint4*)(dst + (size_t)c * ps * ps) = o;
+        }
+    }
+}
+
+// ============================ LayerNorm ======================================
+// One wave per row; the row lives in registers (HIDDEN/256 float4 per lane).
+// Two-pass mean / biased variance in fp32, like nn.LayerNorm (E4/E5/E8).
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>   // NV = hidden / 256
+__device__ __forceinline__ void ln_row(float4 (&v)[NV], const float* __restrict__ g,
+                                       const float* __restrict__ b, int lane, float eps, int hidden) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) / (float)hidden;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 gg = *(const float4*)(g + (i * 64 + lane) * 4);
+        const float4 bb = *(const float4*)(b + (i * 64 + lane) * 4);
+        v[i].x = v[i].x * rstd * gg.x + bb.x; v[i].y = v[i].y * rstd * gg.y + bb.y;
+        v[i].z = v[i].z * rstd * gg.z + bb.z; v[i].w = v[i].w * rstd * gg.w + bb.w;
+    }
+}
+
+// h = LN(x) as bf16 (LN1 / LN2 feeding the next GEMM)
+template <int NV>
+__global__ __launch_bounds__(256)
+void layernorm_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ h,
+                           const float* __restrict__ g, const float* __restrict__ b,
+                           int rows, float eps) {
+    constexpr int H = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)row * H + (i * 64 + lane) * 4);
+    ln_row<NV>(v, g, b, lane, eps, H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_bf16(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+}
+
+// Embedding finish (E3 tail + E4 + first LN1): token 0 of every image is
+// class_embedding + position_embedding[0]; then x = pre_layrnorm(x) in place
+// (fp32 residual stream) and h = layer_norm1[layer 0](x) as bf16.
+template <int NV>
+__global__ __launch_bounds__(256)
+void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
+                         const float* __restrict__ cls, const float* __restrict__ pos0,
+                         const float* __restrict__ g_pre, const float* __restrict__ b_pre,
+                         const float* __restrict__ g_ln1, const float* __restrict__ b_ln1,
+                         int rows, int tokens, float eps) {
+    constexpr int H = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bool is_cls = (row % tokens) == 0;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int o = (i * 64 + lane) * 4;
+        if (is_cls) {
+            const float4 c = *(const float4*)(cls + o), p = *(const float4*)(pos0 + o);
+            v[i] = float4{c.x + p.x, c.y + p.y, c.z + p.z, c.w + p.w};
+        } else {
+            v[i] = *(const float4*)(x + (size_t)row * H + o);
+        }
+    }
+    ln_row<NV>(v, g_pre, b_pre, lane, eps, H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *(float4*)(x + (size_t)row * H + (i * 64 + lane) * 4) = v[i];
+    ln_row<NV>(v, g_ln1, b_ln1, lane, eps, H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_bf16(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+}
+
+// ============================ attention ======================================
+// Single-tile softmax attention for T <= 64 tokens, head_dim = 64 (E6).
+// One wave per (image, head); a 256-thread workgroup covers 4 heads of one image.
+//   S^T = K Q^T   : MFMA A = K rows (key on the register axis), B = Q (query on the lane axis)
+//                   Q arrives pre-scaled by d_h^-0.5 (folded into Wq, bq on the host).
+//   softmax over keys = over registers + the 4 lane groups (fp32, E6 "dtype=float32")
+//   O^T = V^T P^T : P^T is already the B operand of the next MFMA under the k-slot order
+//                   key(s,g,j) = 32 s + 16 (j>>2) + 4 g + (j&3); V^T fragments in that same
+//                   order come from ds_read_b64_tr_b16 on a row-major [64 keys][64 d] LDS tile.
+// qkv: [rows][3*hidden] bf16 (q | k | v);  out: [rows][hidden] bf16.
+__global__ __launch_bounds__(256)
+void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                          int tokens, int hidden, int heads) {
+    __shared__ __attribute__((aligned(16))) uint16_t vlds[4][64 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hgroups = heads >> 2;
+    const int img = blockIdx.x / hgroups;
+    const int head = (blockIdx.x - img * hgroups) * 4 + wave;
+    const int ld = 3 * hidden;
+    const uint16_t* base = qkv + (size_t)img * tokens * ld + head * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
+    uint16_t* vt = vlds[wave];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = it * 64 + lane, row = id >> 3, c = id & 7;
+        uint4 val = {0u, 0u, 0u, 0u};
+        if (row < tokens) val = *(const uint4*)(base + 2 * hidden + (size_t)row * ld + c * 8);
+        *(uint4*)(vt + row * 64 + c * 8) = val;
+    }
+
+    // K (A operand) and Q (B operand) fragments straight from global memory
+    bf16x8 kf[4][2], qf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = t * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
+            if (row < tokens) {
+                kv = *(const uint4*)(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
+                qv = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
+            }
+            kf[t][ks] = __builtin_bit_cast(bf16x8, kv);
+            qf[t][ks] = __builtin_bit_cast(bf16x8, qv);
+        }
+    }
+
+    // S^T[mt][nt]: lane holds keys 16 mt + 4 g + r (r = register), query 16 nt + r16
+    f32x4 s[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt][0], qf[nt][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt][1], qf[nt][1], a, 0, 0, 0);
+            s[mt][nt] = a;
+        }
+
+    // softmax over keys, per query column
+    float inv_sum[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = mt * 16 + g * 4 + r;
+                if (key >= tokens) s[mt][nt][r] = -3.0e38f;
+                mx = fmaxf(mx, s[mt][nt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[mt][nt][r] - mx);     // masked keys: exp(-huge) = 0
+                s[mt][nt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv_sum[nt] = 1.0f / sum;
+    }
+
+    // P^T fragments (B operand): k-slot j<4 -> tile 2s reg j ; j>=4 -> tile 2s+1 reg j-4
+    bf16x8 pf[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const f32x4 lo = s[2 * ss][nt], hi = s[2 * ss + 1][nt];
+            pf[nt][ss] = bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3],
+                                (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+        }
+
+    __syncthreads();   // V tile visible (all 64 lanes active from here on: tr reads need full EXEC)
+
+    // V^T fragments (A operand) by transposed LDS reads.  Lane i=4q+p of a 16-lane group
+    // addresses row q, columns 4p..4p+3 of a 4x16 block and receives column i of its 4 rows.
+    const int q4 = r16 >> 2, p4 = r16 & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x4 o[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const int key0 = 32 * ss + 4 * g + q4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4*)(vt + (key0) * 64 + dt * 16 + p4 * 4));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4*)(vt + (key0 + 16) * 64 + dt * 16 + p4 * 4));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt][ss], o[nt], 0, 0, 0);
+        }
+        // O^T: lane holds d = 16 dt + 4 g + r, query 16 nt + r16
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int qrow = nt * 16 + r16;
+            if (qrow < tokens) {
+                f32x4 v = o[nt];
+                v[0] *= inv_sum[nt]; v[1] *= inv_sum[nt]; v[2] *= inv_sum[nt]; v[3] *= inv_sum[nt];
+                *(uint2*)(out + ((size_t)img * tokens + qrow) * hidden + head * 64 + dt * 16 + g * 4) =
+                    pack4_bf16(v);
+            }
+        }
+    }
+}
+
+// ============================ pooling head ===================================
+// CLS token -> post_layernorm -> visual_projection (fp32 weights, no bias) ->
+// L2 normalise (x / max(||x||, 1e-12), F.normalize)                 (E8-E10)
+// One 256-thread workgroup per image; each wave produces proj_dim/4 outputs,
+// every output a lane-split dot over `hidden` + wave reduction.
+template <int NV>
+__global__ __launch_bounds__(256)
+void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                         const float* __restrict__ b, const float* __restrict__ wproj,
+                         float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
+                         int tokens, int proj_dim, float eps) {
+    constexpr int H = NV * 256;
+    __shared__ float feat[2048];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int img = blockIdx.x;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
+    ln_row<NV>(v, g, b, lane, eps, H);     // every wave normalises the same row (cheap, avoids a broadcast)
+    float ss = 0.f;
+    for (int o = wave; o < proj_dim; o += 4) {
+        const float* wr = wproj + (size_t)o * H;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 w = *(const float4*)(wr + (i * 64 + lane) * 4);
+            acc += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) feat[o] = acc;
+        ss += acc * acc;                    // identical in every lane
+    }
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int o = threadIdx.x; o < proj_dim; o += 256) {
+        const float e = feat[o] / nrm;
+        out_f32[(size_t)img * proj_dim + o] = e;
+        if (out_f16) out_f16[(size_t)img * proj_dim + o] = __builtin_bit_cast(uint16_t, (_Float16)e);
+    }
+}
+
+}  // namespace vq

@@ -1,0 +1,168 @@
+// bf16/fp16 "TN" GEMM on gfx950 MFMA with a fused epilogue functor.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A: [M][K] row-major (activations)
+//                                            W: [N][K] row-major (nn.Linear layout [out,in])
+//
+// Both operands are K-contiguous, so both MFMA fragments are plain 16-byte LDS
+// reads.  The weight fragment is fed as the MFMA "A" operand and the activation
+// fragment as "B": the 16x16 result then has n on the register axis, i.e. each
+// lane owns 4 CONSECUTIVE n for one m, which makes the epilogue's global
+// accesses 8-byte (bf16) / 16-byte (fp32) wide instead of 2-byte scatters.
+//
+// Tile: 128(m) x 128(n) x 64(k) per 256-thread workgroup, 4 waves as 2x2, each
+// wave 64x64 = 4x4 MFMA 16x16x32 tiles.  Staging is LDS-DMA
+// (global_load_lds, 16 B/lane): one wave-instruction fills 8 rows x 128 B; the
+// 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE side (the
+// LDS image itself is lane-linear) and the same XOR is applied on the fragment
+// read, which makes every ds_read_b128 lane group hit 16 distinct 16-B slots of
+// the 256-B bank row (conflict-free; checked with SQ_LDS_BANK_CONFLICT).
+// Double-buffered: the next k-tile's DMA is issued before the MFMAs of the
+// current one.
+//
+// Requirements (checked by the host launcher): M % 128 == 0 (buffers are padded),
+// N % 128 == 0, K % 64 == 0, lda/ldw multiples of 8 elements, 16-B aligned bases.
+#pragma once
+#include "vq_common.h"
+
+namespace vq {
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_LDS_BYTES = 2 * (GEMM_BM + GEMM_BN) * GEMM_BK * 2;   // 64 KiB
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <bool IS_F16> struct mfma_op;
+template <> struct mfma_op<false> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct mfma_op<true> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// XCD-aware bijective remap of the flat workgroup id (blocks b and b+8 share an
+// XCD's L2): each XCD gets a contiguous run of tiles, n fastest, so the A panel
+// of a tile row is re-read from that XCD's L2 by the N/128 tiles that share it.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <bool IS_F16, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+                    const uint16_t* __restrict__ W, int ldw,
+                    int K, int tiles_n, Epi epi) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * GEMM_BM;
+    const int n0 = (wg % tiles_n) * GEMM_BN;
+
+    // ---- staging addresses (per lane source, wave-uniform LDS destination) ----
+    // wave w fills 1-KiB pieces 4w..4w+3 of the A tile and of the W tile.
+    const int srow = lane >> 3;                  // row inside an 8-row piece
+    const int sslot = lane & 7;                  // 16-B slot inside the 128-B row
+    const uint16_t* a_src[4];
+    const uint16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + srow;           // 0..127 inside the tile
+        const int chunk = sslot ^ ((row >> 1) & 7);          // logical k-chunk this slot holds
+        a_src[i] = A + (size_t)(m0 + row) * lda + chunk * 8;
+        w_src[i] = W + (size_t)(n0 + row) * ldw + chunk * 8;
+    }
+    constexpr int TILE_BYTES = GEMM_BM * GEMM_BK * 2;        // 16 KiB per operand tile
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * BUF_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[i] + kt * GEMM_BK),
+                                             (lds_void_t*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[i] + kt * GEMM_BK),
+                                             (lds_void_t*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    // byte offset of (tile-row block t, k-substep ks) for this lane:
+    //   row = 16 t + frow ; slot = (4 ks + fgrp) ^ fx
+    const int a_off = (wm * 64 + frow) * 128;
+    const int w_off = TILE_BYTES + (wn * 64 + frow) * 128;
+    const int slot0 = ((0 + fgrp) ^ fx) * 16, slot1 = ((4 + fgrp) ^ fx) * 16;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / GEMM_BK;
+    stage(0, 0);
+    __syncthreads();          // emits vmcnt(0): the DMA has landed for every wave
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* buf = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = ks ? slot1 : slot0;
+            frag af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const frag*)(buf + a_off + t * 2048 + so);
+                wf[t] = *(const frag*)(buf + w_off + t * 2048 + so);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = op::run(wf[ni], af[mi], acc[mi][ni]);
+        }
+        __syncthreads();      // next buffer landed (vmcnt(0)) and this one is free to refill
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3] ----
+    const int m_base = m0 + wm * 64 + frow;
+    const int n_base = n0 + wn * 64 + fgrp * 4;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                          int M, int N, int K, const Epi& epi) {
+    VQ_CHECK(M > 0 && M % GEMM_BM == 0 && N % GEMM_BN == 0 && K % GEMM_BK == 0 && K >= GEMM_BK,
+             "gemm_tn: shape M=%d N=%d K=%d is not tile-aligned (128/128/64)", M, N, K);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    const int tiles_m = M / GEMM_BM, tiles_n = N / GEMM_BN;
+    hipLaunchKernelGGL((gemm_tn_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, st,
+                       A, lda, W, ldw, K, tiles_n, epi);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vq

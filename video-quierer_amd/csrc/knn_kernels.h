@@ -1,0 +1,153 @@
+// Device kernels of the exact cosine k-NN scan.
+//   distance = fp32(1 - fp32(dot(row, q))),  result = k smallest by (distance, row)
+// dot is the fixed-order fp64 chain of oracle/knn_oracle.c, so ids and
+// distances are bit-identical to the oracle.
+#pragma once
+#include "vq_common.h"
+
+namespace vq {
+
+// (distance, row) -> one 64-bit key whose unsigned order is the lexicographic
+// (distance asc, row asc) order of hnsw.py:269 `sorted(candidates)[:k]`.
+__host__ __device__ inline uint64_t dist_key(float d, uint32_t row) {
+    uint32_t u = __builtin_bit_cast(uint32_t, d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone float -> uint
+    return ((uint64_t)u << 32) | row;
+}
+__host__ __device__ inline float key_dist(uint64_t k) {
+    uint32_t u = (uint32_t)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+
+// ---- row normalisation (HNSWIndex.add, hnsw.py:157) for device-resident rows ----
+// n2 = fp64 chain of x*x in index order; x <- fp32(x / fp32(sqrt(n2))).
+// One thread per row keeps the chain order; rows are staged through LDS in
+// 64-float column panels so the global reads stay coalesced.
+constexpr int NORM_ROWS = 128;   // rows (= threads) per workgroup
+__global__ __launch_bounds__(NORM_ROWS)
+void normalize_rows_kernel(float* __restrict__ rows, int64_t n, int dim) {
+    __shared__ float tile[NORM_ROWS][65];
+    __shared__ float nrm[NORM_ROWS];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * NORM_ROWS;
+    double acc = 0.0;
+    for (int d0 = 0; d0 < dim; d0 += 64) {
+        for (int i = tid; i < NORM_ROWS * 64; i += NORM_ROWS) {
+            const int rr = i >> 6, cc = i & 63;
+            const int64_t r = r0 + rr;
+            tile[rr][cc] = (r < n && d0 + cc < dim) ? rows[r * dim + d0 + cc] : 0.f;
+        }
+        __syncthreads();
+        const int lim = min(64, dim - d0);
+        for (int c = 0; c < lim; ++c) { const double v = (double)tile[tid][c]; acc += v * v; }
+        __syncthreads();
+    }
+    nrm[tid] = (float)sqrt(acc);
+    __syncthreads();
+    for (int64_t i = tid; i < (int64_t)NORM_ROWS * dim; i += NORM_ROWS) {
+        const int rr = (int)(i / dim);
+        const int64_t r = r0 + rr;
+        if (r < n) rows[r * dim + (i - (int64_t)rr * dim)] /= nrm[rr];      // IEEE fp32 division
+    }
+}
+
+// fp32 master -> fp16 scan copy (round-to-nearest-even)
+__global__ __launch_bounds__(256)
+void rows_to_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t count4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = *(const float4*)(src + i * 4);
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *(uint2*)(dst + i * 4) = __builtin_bit_cast(uint2, h);
+    }
+}
+
+// ---- exact distances ----
+// Workgroup tile: 64 rows x 32 queries, 256 threads; thread (r = tid&63, g = tid>>6)
+// owns row r and queries 8g..8g+7 (a wave shares g, so query reads are LDS broadcasts).
+// The k loop runs in index order over 64-wide panels: acc += (double)x[i]*(double)q[i].
+__global__ __launch_bounds__(256)
+void exact_dist_kernel(const float* __restrict__ rows, int64_t n, int dim,
+                       const float* __restrict__ queries, int nq,
+                       float* __restrict__ dist /*[nq][ld]*/, int64_t ld) {
+    __shared__ float xs[64][65];
+    __shared__ double qs[32][64];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int q0 = blockIdx.y * 32;
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int d0 = 0; d0 < dim; d0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int rr = i >> 6, cc = i & 63;
+            const int64_t gr = row0 + rr;
+            xs[rr][cc] = (gr < n && d0 + cc < dim) ? rows[gr * dim + d0 + cc] : 0.f;
+        }
+        for (int i = tid; i < 32 * 64; i += 256) {
+            const int qq = i >> 6, cc = i & 63;
+            qs[qq][cc] = (q0 + qq < nq && d0 + cc < dim) ? (double)queries[(int64_t)(q0 + qq) * dim + d0 + cc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const double xv = (double)xs[r][c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += xv * qs[g * 8 + j][c];   // product exact in fp64
+        }
+        __syncthreads();
+    }
+    const int64_t gr = row0 + r;
+    if (gr < n) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = q0 + g * 8 + j;
+            if (q < nq) dist[(int64_t)q * ld + gr] = 1.0f - (float)acc[j];
+        }
+    }
+}
+
+// ---- exact selection ----
+// One workgroup per query: k rounds of "smallest key strictly above the previous one".
+// Keys are unique (row is part of the key), so round j yields rank j exactly.
+__global__ __launch_bounds__(256)
+void select_topk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k,
+                        int32_t* __restrict__ ids, float* __restrict__ out_dist) {
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t prev_s;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* d = dist + (int64_t)q * ld;
+    uint64_t prev = 0;
+    bool have_prev = false;
+    for (int j = 0; j < k; ++j) {
+        uint64_t best = ~0ull;
+        for (int64_t i = tid; i < n; i += 256) {
+            const uint64_t key = dist_key(d[i], (uint32_t)i);
+            if ((!have_prev || key > prev) && key < best) best = key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t b = red[0];
+            for (int w = 1; w < 4; ++w) b = red[w] < b ? red[w] : b;
+            prev_s = b;
+            if (b == ~0ull) { ids[(int64_t)q * k + j] = -1; out_dist[(int64_t)q * k + j] = __builtin_inff(); }
+            else { ids[(int64_t)q * k + j] = (int32_t)(uint32_t)b; out_dist[(int64_t)q * k + j] = key_dist(b); }
+        }
+        __syncthreads();
+        prev = prev_s;
+        have_prev = true;
+        if (prev == ~0ull) {            // exhausted: fill the rest
+            for (int jj = j + 1 + tid; jj < k; jj += 256) { ids[(int64_t)q * k + jj] = -1; out_dist[(int64_t)q * k + jj] = __builtin_inff(); }
+            break;
+        }
+    }
+}
+
+}  // namespace vq

@@ -1,0 +1,63 @@
+// Shared host/device helpers for libvq_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/vq_amd.h"
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+
+namespace vq {
+
+// ---- error plumbing -------------------------------------------------------
+// Every C-ABI entry point returns 0 or a negative code and leaves a message in
+// a thread-local buffer (vq_last_error), mirroring the reference convention
+// "log + raise" (reference src/core/feature_extractor.py:175-177).
+// Codes are the VQ_* macros of include/vq_amd.h (INVALID: bad argument or unsupported
+// geometry; HIP: runtime failure; STATE: library not initialised; OOM).
+
+std::string& last_error();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define VQ_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::vq::fail(VQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                              hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+#define VQ_CHECK(cond, ...)                                                               \
+    do {                                                                                  \
+        if (!(cond)) return ::vq::fail(VQ_ERR_INVALID, __VA_ARGS__);                \
+    } while (0)
+
+#define VQ_TRY(expr)                                                                      \
+    do {                                                                                  \
+        int rc__ = (expr);                                                                \
+        if (rc__ != 0) return rc__;                                                       \
+    } while (0)
+
+// ---- device-side types ----------------------------------------------------
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef uint16_t f16_t;    // raw fp16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__host__ __device__ inline uint16_t f32_to_bf16_rne(float f) {
+    // round-to-nearest-even on the fp32 bits; NaN stays NaN (quiet)
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(uint16_t h) {
+    return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace vq

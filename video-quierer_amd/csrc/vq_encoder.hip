@@ -1,0 +1,431 @@
+// vq_encoder: CLIP ViT image-encoder forward pass on one MI355X.
+// Replaces FeatureExtractor._load_model / extract_batch
+// (reference src/core/feature_extractor.py:70-103, 137-177) and the
+// transformers CLIP vision tower it calls.
+#include "../../include/vq_amd.h"
+#include "vq_common.h"
+#include "gemm_mfma.h"
+#include "encoder_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace vq {
+int require_init();
+
+enum EncClass { C_PATCHIFY = 0, C_GEMM_PATCH, C_EMBED_FINISH, C_LAYERNORM, C_GEMM_QKV, C_ATTENTION,
+                C_GEMM_OUT, C_GEMM_FC1, C_GEMM_FC2, C_POOL };
+static const char* kEncClassNames[VQ_ENC_NCLASS] = {
+    "patchify_u8", "gemm_patch_embed", "embed_finish_ln", "layernorm_bf16", "gemm_qkv",
+    "attention_t64", "gemm_out_proj_residual", "gemm_fc1_quickgelu", "gemm_fc2_residual", "pool_project"};
+
+struct LayerW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_qkv, *b_out, *b_fc1, *b_fc2;
+    uint16_t *w_qkv, *w_out, *w_fc1, *w_fc2;
+};
+
+struct Arena {            // one hipMalloc, 256-B aligned bump allocation
+    char* base = nullptr; size_t size = 0, used = 0;
+    template <class T> T* take(size_t count) {
+        used = (used + 255) & ~(size_t)255;
+        T* p = (T*)(base + used);
+        used += count * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace vq
+
+using namespace vq;
+
+struct vq_encoder {
+    vq_vit_config cfg{};
+    int tokens = 0, patches = 0, grid = 0, patch_k = 0, max_batch = 0;
+    int64_t rows_pad = 0, prow_pad = 0;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // created by the handle
+    std::mutex mu;
+    Arena arena;
+    // weights
+    uint16_t* w_patch = nullptr; float *b_patch = nullptr, *cls = nullptr, *pos = nullptr;
+    float *pre_g = nullptr, *pre_b = nullptr, *post_g = nullptr, *post_b = nullptr, *w_proj = nullptr;
+    std::vector<LayerW> layers;
+    // workspace
+    uint8_t* d_frames = nullptr;
+    float *x = nullptr, *d_out = nullptr;
+    uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    int run_layers = -1;
+    int last_n = 0;
+    // profiling
+    bool profiling = false;
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+struct Prof {             // brackets one launch with events when profiling
+    vq_encoder* e; int cls; hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(vq_encoder* e) {
+        if (!e->pool.empty()) { hipEvent_t ev = e->pool.back(); e->pool.pop_back(); return ev; }
+        hipEvent_t ev; (void)hipEventCreate(&ev); return ev;
+    }
+    Prof(vq_encoder* enc, int c) : e(enc), cls(c) {
+        if (e->profiling) { a = get(e); b = get(e); (void)hipEventRecord(a, e->stream); }
+    }
+    ~Prof() {
+        if (e->profiling) { (void)hipEventRecord(b, e->stream); e->events.push_back({cls, a, b}); }
+    }
+};
+
+size_t arena_bytes(const vq_vit_config& c, int tokens, int patches, int patch_k, int max_batch,
+                   int64_t rows_pad, int64_t prow_pad) {
+    size_t h = c.hidden, m = c.mlp, n = 0;
+    auto add = [&](size_t bytes) { n = ((n + 255) & ~(size_t)255) + bytes; };
+    add((size_t)h * patch_k * 2); add(h * 4); add(h * 4); add((size_t)tokens * h * 4);
+    add(h * 4); add(h * 4); add(h * 4); add(h * 4); add((size_t)c.proj_dim * h * 4);
+    for (int l = 0; l < c.layers; ++l) {
+        for (int i = 0; i < 4; ++i) add(h * 4);
+        add(3 * h * 4); add(h * 4); add(m * 4); add(h * 4);
+        add(3 * h * h * 2); add(h * h * 2); add(m * h * 2); add(h * m * 2);
+    }
+    add((size_t)max_batch * c.image_size * c.image_size * 3);
+    add((size_t)rows_pad * h * 4); add((size_t)max_batch * c.proj_dim * 4);
+    add((size_t)rows_pad * h * 2); add((size_t)rows_pad * 3 * h * 2); add((size_t)rows_pad * h * 2);
+    size_t mlp_elems = std::max((size_t)rows_pad * m, (size_t)prow_pad * patch_k);
+    add(mlp_elems * 2);
+    (void)patches;
+    return n + 4096;
+}
+
+int upload_f32(float* dst, const float* src, size_t n) {
+    VQ_HIP(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+int upload_bf16(uint16_t* dst, const float* src, size_t n, float scale = 1.0f) {
+    std::vector<uint16_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_rne(src[i] * scale);
+    VQ_HIP(hipMemcpy(dst, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <int NV>
+int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
+    const vq_vit_config& c = e->cfg;
+    hipStream_t st = e->stream;
+    const int H = c.hidden, T = e->tokens;
+    const int rows = n * T;
+    const int rows_gemm = (int)round_up(rows, GEMM_BM);
+    const int prows = n * e->patches;
+    const int prows_gemm = (int)round_up(prows, GEMM_BM);
+
+    {   // E1/E2 + im2col: uint8 frames -> bf16 patch rows (aliases the MLP buffer)
+        Prof p(e, C_PATCHIFY);
+        const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
+        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(patchify_u8_kernel, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+                           c.image_size, c.patch_size, swap_rb);
+    }
+    {   // E3: patch-embedding conv as a GEMM, epilogue scatters into token rows + position embedding
+        Prof p(e, C_GEMM_PATCH);
+        VQ_TRY((launch_gemm_tn<false>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
+                                      EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows})));
+    }
+    const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
+    {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
+        Prof p(e, C_EMBED_FINISH);
+        const LayerW& L0 = e->layers[0];
+        hipLaunchKernelGGL((embed_finish_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
+                           e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
+    }
+    for (int l = 0; l < nl; ++l) {
+        const LayerW& L = e->layers[l];
+        if (l > 0) {
+            Prof p(e, C_LAYERNORM);
+            hipLaunchKernelGGL((layernorm_bf16_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
+                               L.ln1_g, L.ln1_b, rows, c.ln_eps);
+        }
+        {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
+            Prof p(e, C_GEMM_QKV);
+            VQ_TRY((launch_gemm_tn<false>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
+                                          EpiBiasBf16{e->qkv, 3 * H, L.b_qkv})));
+        }
+        {
+            Prof p(e, C_ATTENTION);
+            hipLaunchKernelGGL(attention_t64_kernel, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
+                               c.heads);
+        }
+        {
+            Prof p(e, C_GEMM_OUT);
+            VQ_TRY((launch_gemm_tn<false>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
+                                          EpiBiasResidualF32{e->x, H, L.b_out})));
+        }
+        {
+            Prof p(e, C_LAYERNORM);
+            hipLaunchKernelGGL((layernorm_bf16_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
+                               L.ln2_g, L.ln2_b, rows, c.ln_eps);
+        }
+        {   // E7: fc1 + quick_gelu
+            Prof p(e, C_GEMM_FC1);
+            VQ_TRY((launch_gemm_tn<false>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
+                                          EpiBiasQuickGeluBf16{e->mlp, c.mlp, L.b_fc1})));
+        }
+        {
+            Prof p(e, C_GEMM_FC2);
+            VQ_TRY((launch_gemm_tn<false>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
+                                          EpiBiasResidualF32{e->x, H, L.b_fc2})));
+        }
+    }
+    {   // E8-E10
+        Prof p(e, C_POOL);
+        hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(n), dim3(256), 0, st, e->x, e->post_g, e->post_b,
+                           e->w_proj, d_out_f32, d_out_f16, T, c.proj_dim, c.ln_eps);
+    }
+    VQ_HIP(hipGetLastError());
+    e->last_n = n;
+    return 0;
+}
+
+int forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
+    switch (e->cfg.hidden / 256) {
+        case 3: return run_forward<3>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        case 4: return run_forward<4>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        default: return fail(VQ_ERR_INVALID, "unsupported hidden size %d", e->cfg.hidden);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int n_weights, int max_batch,
+                      vq_encoder** out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(cfg && weights && out, "vq_encoder_create: null argument");
+    const vq_vit_config c = *cfg;
+    VQ_CHECK(c.layers > 0 && n_weights == 5 + 16 * c.layers + 3, "vq_encoder_create: expected %d weight tensors, got %d",
+             5 + 16 * c.layers + 3, n_weights);
+    VQ_CHECK(max_batch > 0 && max_batch <= 8192, "vq_encoder_create: max_batch %d out of range", max_batch);
+    VQ_CHECK(c.image_size % c.patch_size == 0 && c.image_size % 8 == 0 && c.patch_size % 8 == 0,
+             "vq_encoder_create: image %d / patch %d: this build needs patch_size %% 8 == 0", c.image_size, c.patch_size);
+    const int grid = c.image_size / c.patch_size, patches = grid * grid, tokens = patches + 1;
+    VQ_CHECK(tokens <= 64, "vq_encoder_create: %d tokens; the single-tile attention kernel covers <= 64 "
+             "(ViT-L/14@336 needs the streaming attention kernel, not built yet)", tokens);
+    VQ_CHECK(c.hidden % c.heads == 0 && c.hidden / c.heads == 64, "vq_encoder_create: head_dim must be 64");
+    VQ_CHECK(c.heads % 4 == 0, "vq_encoder_create: heads must be a multiple of 4");
+    VQ_CHECK((c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0, "vq_encoder_create: hidden %d / mlp %d unsupported",
+             c.hidden, c.mlp);
+    VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 2048, "vq_encoder_create: proj_dim %d out of range", c.proj_dim);
+    const int patch_k_raw = 3 * c.patch_size * c.patch_size;
+    const int patch_k = (int)round_up(patch_k_raw, GEMM_BK);
+    VQ_CHECK(patch_k == patch_k_raw, "vq_encoder_create: patch K %d must be a multiple of 64", patch_k_raw);
+
+    vq_encoder* e = new vq_encoder();
+    e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
+    e->rows_pad = round_up((int64_t)max_batch * tokens, 256);
+    e->prow_pad = round_up((int64_t)max_batch * patches, 256);
+    auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
+
+    const size_t bytes = arena_bytes(c, tokens, patches, patch_k, max_batch, e->rows_pad, e->prow_pad);
+    hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
+    if (he != hipSuccess) { delete e; return fail(VQ_ERR_OOM, "vq_encoder_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
+    e->arena.size = bytes;
+    he = hipMemset(e->arena.base, 0, bytes);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
+    he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he)));
+    e->stream = e->own_stream;
+
+    Arena& A = e->arena;
+    const size_t H = c.hidden, M = c.mlp;
+    int wi = 0;
+    int rc = 0;
+#define UP(expr) do { rc = (expr); if (rc) return cleanup(rc); } while (0)
+    // embeddings.  Patch weights absorb ToTensor (/255) and Normalize ((x-mean)/std): the
+    // patchify kernel stores (pixel-128), so W' = W/(255 std_c), bias = sum W (128/255-mean_c)/std_c.
+    static const double mean[3] = {0.48145466, 0.4578275, 0.40821073};
+    static const double stdv[3] = {0.26862954, 0.26130258, 0.27577711};
+    e->cls = A.take<float>(H);                UP(upload_f32(e->cls, weights[wi++], H));
+    {
+        const float* wp = weights[wi++];
+        const int pp = c.patch_size * c.patch_size;
+        std::vector<uint16_t> w16(H * patch_k);
+        std::vector<float> bias(H);
+        for (size_t n = 0; n < H; ++n) {
+            double b = 0.0;
+            for (int ch = 0; ch < 3; ++ch)
+                for (int i = 0; i < pp; ++i) {
+                    const double w = wp[(n * 3 + ch) * pp + i];
+                    w16[n * patch_k + ch * pp + i] = f32_to_bf16_rne((float)(w / (255.0 * stdv[ch])));
+                    b += w * (128.0 / 255.0 - mean[ch]) / stdv[ch];
+                }
+            bias[n] = (float)b;
+        }
+        e->w_patch = A.take<uint16_t>(H * patch_k);
+        he = hipMemcpy(e->w_patch, w16.data(), w16.size() * 2, hipMemcpyHostToDevice);
+        if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "weight upload failed: %s", hipGetErrorString(he)));
+        e->b_patch = A.take<float>(H);        UP(upload_f32(e->b_patch, bias.data(), H));
+    }
+    e->pos = A.take<float>((size_t)tokens * H);  UP(upload_f32(e->pos, weights[wi++], (size_t)tokens * H));
+    e->pre_g = A.take<float>(H);              UP(upload_f32(e->pre_g, weights[wi++], H));
+    e->pre_b = A.take<float>(H);              UP(upload_f32(e->pre_b, weights[wi++], H));
+    e->layers.resize(c.layers);
+    const float qscale = 1.0f / std::sqrt((float)(c.hidden / c.heads));   // 0.125: exact in bf16
+    for (int l = 0; l < c.layers; ++l) {
+        LayerW& L = e->layers[l];
+        L.ln1_g = A.take<float>(H);           UP(upload_f32(L.ln1_g, weights[wi++], H));
+        L.ln1_b = A.take<float>(H);           UP(upload_f32(L.ln1_b, weights[wi++], H));
+        L.w_qkv = A.take<uint16_t>(3 * H * H);
+        L.b_qkv = A.take<float>(3 * H);
+        for (int part = 0; part < 3; ++part) {        // q, k, v
+            const float s = part == 0 ? qscale : 1.0f;
+            UP(upload_bf16(L.w_qkv + part * H * H, weights[wi++], H * H, s));
+            std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
+            for (auto& v : b) v *= s;
+            UP(upload_f32(L.b_qkv + part * H, b.data(), H));
+        }
+        L.w_out = A.take<uint16_t>(H * H);    UP(upload_bf16(L.w_out, weights[wi++], H * H));
+        L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
+        L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
+        L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
+        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_bf16(L.w_fc1, weights[wi++], M * H));
+        L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
+        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_bf16(L.w_fc2, weights[wi++], H * M));
+        L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
+    }
+    e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));
+    e->post_b = A.take<float>(H);             UP(upload_f32(e->post_b, weights[wi++], H));
+    e->w_proj = A.take<float>((size_t)c.proj_dim * H);
+    UP(upload_f32(e->w_proj, weights[wi++], (size_t)c.proj_dim * H));
+#undef UP
+    // workspace
+    e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
+    e->x = A.take<float>((size_t)e->rows_pad * H);
+    e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
+    e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
+    e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * patch_k));
+    if (A.used > A.size) return cleanup(fail(VQ_ERR_STATE, "arena overflow (%zu > %zu)", A.used, A.size));
+    *out = e;
+    return 0;
+}
+
+int vq_encoder_destroy(vq_encoder* e) {
+    if (!e) return 0;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    for (auto& ev : e->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    if (e->arena.base) (void)hipFree(e->arena.base);
+    delete e;
+    return 0;
+}
+
+int vq_encoder_output_dim(vq_encoder* e, int* dim) {
+    VQ_CHECK(e && dim, "vq_encoder_output_dim: null argument");
+    *dim = e->cfg.proj_dim;
+    return 0;
+}
+
+int vq_encoder_encode_u8_device(vq_encoder* e, const void* d_frames, int n, int swap_rb, void* d_out_f32,
+                                void* d_out_f16) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && d_frames && d_out_f32, "vq_encoder_encode_u8_device: null argument");
+    VQ_CHECK(n > 0 && n <= e->max_batch, "vq_encoder_encode_u8_device: n=%d outside (0, max_batch=%d]", n, e->max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    return forward(e, (const uint8_t*)d_frames, n, swap_rb, (float*)d_out_f32, (uint16_t*)d_out_f16);
+}
+
+int vq_encoder_encode_u8(vq_encoder* e, const uint8_t* frames, int n, int swap_rb, float* out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && n >= 0 && (n == 0 || (frames && out)), "vq_encoder_encode_u8: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t fbytes = (size_t)e->cfg.image_size * e->cfg.image_size * 3;
+    for (int done = 0; done < n; done += e->max_batch) {
+        const int cur = std::min(e->max_batch, n - done);
+        VQ_HIP(hipMemcpyAsync(e->d_frames, frames + (size_t)done * fbytes, cur * fbytes, hipMemcpyHostToDevice, e->stream));
+        VQ_TRY(forward(e, e->d_frames, cur, swap_rb, e->d_out, nullptr));
+        VQ_HIP(hipMemcpyAsync(out + (size_t)done * e->cfg.proj_dim, e->d_out, (size_t)cur * e->cfg.proj_dim * 4,
+                              hipMemcpyDeviceToHost, e->stream));
+        VQ_HIP(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+int vq_encoder_synchronize(vq_encoder* e) {
+    VQ_CHECK(e, "vq_encoder_synchronize: null handle");
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int vq_encoder_set_stream(vq_encoder* e, void* hip_stream) {
+    VQ_CHECK(e, "vq_encoder_set_stream: null handle");
+    std::lock_guard<std::mutex> lk(e->mu);
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return 0;
+}
+
+int vq_encoder_profile_begin(vq_encoder* e) {
+    VQ_CHECK(e, "vq_encoder_profile_begin: null handle");
+    std::lock_guard<std::mutex> lk(e->mu);
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    for (auto& ev : e->events) { e->pool.push_back(ev.a); e->pool.push_back(ev.b); }
+    e->events.clear();
+    e->profiling = true;
+    return 0;
+}
+
+int vq_encoder_profile_end(vq_encoder* e, float* ms, int* launches) {
+    VQ_CHECK(e && ms && launches, "vq_encoder_profile_end: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->profiling = false;
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < VQ_ENC_NCLASS; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    for (auto& ev : e->events) {
+        float t = 0.f;
+        VQ_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
+        ms[ev.cls] += t; launches[ev.cls] += 1;
+        e->pool.push_back(ev.a); e->pool.push_back(ev.b);
+    }
+    e->events.clear();
+    return 0;
+}
+
+const char* vq_encoder_profile_class_name(int cls) {
+    return (cls >= 0 && cls < VQ_ENC_NCLASS) ? kEncClassNames[cls] : "";
+}
+
+int vq_encoder_debug_set_layers(vq_encoder* e, int layers) {
+    VQ_CHECK(e, "vq_encoder_debug_set_layers: null handle");
+    e->run_layers = layers;
+    return 0;
+}
+
+int vq_encoder_debug_read(vq_encoder* e, const char* name, int rows, float* out) {
+    VQ_CHECK(e && name && out, "vq_encoder_debug_read: null argument");
+    VQ_CHECK(rows > 0 && rows <= e->rows_pad, "vq_encoder_debug_read: rows out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    const size_t H = e->cfg.hidden;
+    if (!strcmp(name, "x")) {
+        VQ_HIP(hipMemcpy(out, e->x, (size_t)rows * H * 4, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const uint16_t* src = nullptr; size_t cols = 0;
+    if (!strcmp(name, "h")) { src = e->h; cols = H; }
+    else if (!strcmp(name, "qkv")) { src = e->qkv; cols = 3 * H; }
+    else if (!strcmp(name, "att")) { src = e->att; cols = H; }
+    else if (!strcmp(name, "mlp")) { src = e->mlp; cols = e->cfg.mlp; }
+    else return fail(VQ_ERR_INVALID, "vq_encoder_debug_read: unknown buffer '%s'", name);
+    std::vector<uint16_t> tmp((size_t)rows * cols);
+    VQ_HIP(hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) out[i] = bf16_to_f32(tmp[i]);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// vq_index: exact cosine k-NN over a device-resident embedding matrix.
+// Replaces HNSWIndex.add / add_batch / search / search_batch / size and backs
+// save / load (reference src/indexes/hnsw.py:150-380, 488-528) — SURVEY.md §8a K-rows.
+#include "../../include/vq_amd.h"
+#include "vq_common.h"
+#include "knn_kernels.h"
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace vq {
+int require_init();
+enum IdxClass { I_NORMALIZE = 0, I_TO_F16, I_EXACT_DIST, I_SELECT, I_MFMA_SCAN, I_RESCORE };
+static const char* kIdxClassNames[VQ_IDX_NCLASS] = {
+    "normalize_rows", "rows_to_f16", "exact_dist_f64chain", "select_topk", "scan_f16_mfma_top2", "rescore_verify"};
+}  // namespace vq
+
+using namespace vq;
+
+struct vq_index {
+    int dim = 0;
+    int64_t size = 0, cap = 0;
+    float* rows = nullptr;        // fp32 master [cap][dim] (normalised rows, what the reference keeps in .data)
+    uint16_t* rows16 = nullptr;   // fp16 scan copy [cap][dim]
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    std::mutex mu;
+    // scratch
+    float* d_q = nullptr; int64_t q_cap = 0;          // queries [q_cap][dim]
+    float* d_dist = nullptr; int64_t dist_cap = 0;    // exact distances (elements)
+    int32_t* d_ids = nullptr; float* d_out = nullptr; int64_t out_cap = 0;
+    int64_t stats[3] = {0, 0, 0};
+    bool profiling = false;
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+struct Prof {
+    vq_index* x; int cls; hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(vq_index* x) {
+        if (!x->pool.empty()) { hipEvent_t ev = x->pool.back(); x->pool.pop_back(); return ev; }
+        hipEvent_t ev; (void)hipEventCreate(&ev); return ev;
+    }
+    Prof(vq_index* i, int c) : x(i), cls(c) {
+        if (x->profiling) { a = get(x); b = get(x); (void)hipEventRecord(a, x->stream); }
+    }
+    ~Prof() { if (x->profiling) { (void)hipEventRecord(b, x->stream); x->events.push_back({cls, a, b}); } }
+};
+
+int reserve_rows(vq_index* x, int64_t need) {
+    if (need <= x->cap) return 0;
+    int64_t ncap = std::max<int64_t>(need, std::max<int64_t>(1024, x->cap * 2));
+    ncap = round_up(ncap, 256);
+    float* nr = nullptr; uint16_t* nh = nullptr;
+    hipError_t e = hipMalloc((void**)&nr, (size_t)ncap * x->dim * 4);
+    if (e != hipSuccess) return fail(VQ_ERR_OOM, "index: hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
+    e = hipMalloc((void**)&nh, (size_t)ncap * x->dim * 2);
+    if (e != hipSuccess) { (void)hipFree(nr); return fail(VQ_ERR_OOM, "index: hipMalloc (fp16 copy) failed: %s", hipGetErrorString(e)); }
+    VQ_HIP(hipMemsetAsync(nh, 0, (size_t)ncap * x->dim * 2, x->stream));   // pad rows of the scan copy stay finite
+    if (x->size > 0) {
+        VQ_HIP(hipMemcpyAsync(nr, x->rows, (size_t)x->size * x->dim * 4, hipMemcpyDeviceToDevice, x->stream));
+        VQ_HIP(hipMemcpyAsync(nh, x->rows16, (size_t)x->size * x->dim * 2, hipMemcpyDeviceToDevice, x->stream));
+    }
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    (void)hipFree(x->rows); (void)hipFree(x->rows16);
+    x->rows = nr; x->rows16 = nh; x->cap = ncap;
+    return 0;
+}
+
+template <class T> int reserve_buf(T*& p, int64_t& cap, int64_t need) {
+    if (need <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc((void**)&p, (size_t)need * sizeof(T));
+    if (e != hipSuccess) return fail(VQ_ERR_OOM, "index: scratch hipMalloc(%lld) failed: %s", (long long)(need * sizeof(T)), hipGetErrorString(e));
+    cap = need;
+    return 0;
+}
+
+// rows already on the device at x->rows + size*dim
+int finish_add(vq_index* x, int64_t n, int normalize) {
+    float* dst = x->rows + x->size * x->dim;
+    if (normalize) {
+        Prof p(x, I_NORMALIZE);
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, NORM_ROWS)), dim3(NORM_ROWS), 0, x->stream, dst, n, x->dim);
+    }
+    {
+        Prof p(x, I_TO_F16);
+        const int64_t count4 = n * x->dim / 4;
+        const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(rows_to_f16_kernel, dim3(blocks), dim3(256), 0, x->stream, dst,
+                           x->rows16 + x->size * x->dim, count4);
+    }
+    VQ_HIP(hipGetLastError());
+    x->size += n;
+    return 0;
+}
+
+// Exact scan: fp64-chain distances for a slice of queries into d_dist, then selection.
+int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
+    const int64_t n = x->size;
+    const int64_t ld = round_up(n, 64);
+    const int64_t budget = (int64_t)128 << 20;                 // 512 MiB of fp32 distances per slice
+    int qslice = (int)std::max<int64_t>(32, std::min<int64_t>(nq, budget / ld) / 32 * 32);
+    VQ_TRY(reserve_buf(x->d_dist, x->dist_cap, (int64_t)std::min(qslice, (int)round_up(nq, 32)) * ld));
+    for (int q0 = 0; q0 < nq; q0 += qslice) {
+        const int cur = std::min(qslice, nq - q0);
+        {
+            Prof p(x, I_EXACT_DIST);
+            hipLaunchKernelGGL(exact_dist_kernel, dim3(cdiv(n, 64), cdiv(cur, 32)), dim3(256), 0, x->stream, x->rows, n,
+                               x->dim, d_queries + (int64_t)q0 * x->dim, cur, x->d_dist, ld);
+        }
+        {
+            Prof p(x, I_SELECT);
+            hipLaunchKernelGGL(select_topk_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_dist, ld, n, k,
+                               d_ids + (int64_t)q0 * k, d_dist_out + (int64_t)q0 * k);
+        }
+    }
+    VQ_HIP(hipGetLastError());
+    x->stats[0] = 0; x->stats[1] = 0; x->stats[2] = nq;
+    return 0;
+}
+
+int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
+    VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
+    VQ_CHECK(mode != 2, "vq_index_search: mode 2 (fp16 MFMA scan) is not built yet");
+    return search_exact(x, d_queries, nq, k, d_ids, d_dist);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vq_index_create(int dim, vq_index** out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(out && dim > 0 && dim % 4 == 0 && dim <= 4096, "vq_index_create: dim %d must be a positive multiple of 4", dim);
+    vq_index* x = new vq_index();
+    x->dim = dim;
+    hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete x; return fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    x->stream = x->own_stream;
+    *out = x;
+    return 0;
+}
+
+int vq_index_destroy(vq_index* x) {
+    if (!x) return 0;
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->own_stream) (void)hipStreamDestroy(x->own_stream);
+    for (auto& ev : x->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto ev : x->pool) (void)hipEventDestroy(ev);
+    (void)hipFree(x->rows); (void)hipFree(x->rows16); (void)hipFree(x->d_q); (void)hipFree(x->d_dist);
+    (void)hipFree(x->d_ids); (void)hipFree(x->d_out);
+    delete x;
+    return 0;
+}
+
+int vq_index_size(vq_index* x, int64_t* n) {
+    VQ_CHECK(x && n, "vq_index_size: null argument");
+    *n = x->size;
+    return 0;
+}
+
+int vq_index_clear(vq_index* x) {
+    VQ_CHECK(x, "vq_index_clear: null handle");
+    std::lock_guard<std::mutex> lk(x->mu);
+    x->size = 0;
+    return 0;
+}
+
+int vq_index_add(vq_index* x, const float* rows, int64_t n, int normalize) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && n >= 0 && (n == 0 || rows), "vq_index_add: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(x->mu);
+    VQ_CHECK(x->size + n < ((int64_t)1 << 31), "vq_index_add: more than 2^31 rows");
+    VQ_TRY(reserve_rows(x, x->size + n));
+    VQ_HIP(hipMemcpyAsync(x->rows + x->size * x->dim, rows, (size_t)n * x->dim * 4, hipMemcpyHostToDevice, x->stream));
+    VQ_TRY(finish_add(x, n, normalize));
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
+int vq_index_add_device(vq_index* x, const void* d_rows, int64_t n, int normalize) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && n >= 0 && (n == 0 || d_rows), "vq_index_add_device: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(x->mu);
+    VQ_CHECK(x->size + n < ((int64_t)1 << 31), "vq_index_add_device: more than 2^31 rows");
+    VQ_TRY(reserve_rows(x, x->size + n));
+    VQ_HIP(hipMemcpyAsync(x->rows + x->size * x->dim, d_rows, (size_t)n * x->dim * 4, hipMemcpyDeviceToDevice, x->stream));
+    return finish_add(x, n, normalize);
+}
+
+int vq_index_search_device(vq_index* x, const void* d_queries, int nq, int k, int mode, void* d_ids, void* d_dist) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && nq >= 0 && k > 0 && k <= 1024 && (nq == 0 || (d_queries && d_ids && d_dist)), "vq_index_search_device: bad argument");
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(x->mu);
+    return search_dispatch(x, (const float*)d_queries, nq, k, mode, (int32_t*)d_ids, (float*)d_dist);
+}
+
+int vq_index_search(vq_index* x, const float* queries, int nq, int k, int mode, int32_t* ids, float* dist) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && nq >= 0 && k > 0 && k <= 1024 && (nq == 0 || (queries && ids && dist)), "vq_index_search: bad argument");
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->size == 0) {                       // empty index: no candidates (hnsw.py:243-244 returns [])
+        for (int64_t i = 0; i < (int64_t)nq * k; ++i) { ids[i] = -1; dist[i] = __builtin_inff(); }
+        return 0;
+    }
+    VQ_TRY(reserve_buf(x->d_q, x->q_cap, (int64_t)nq * x->dim));
+    if ((int64_t)nq * k > x->out_cap) {
+        int64_t c1 = x->out_cap, c2 = x->out_cap;
+        VQ_TRY(reserve_buf(x->d_ids, c1, (int64_t)nq * k));
+        VQ_TRY(reserve_buf(x->d_out, c2, (int64_t)nq * k));
+        x->out_cap = (int64_t)nq * k;
+    }
+    VQ_HIP(hipMemcpyAsync(x->d_q, queries, (size_t)nq * x->dim * 4, hipMemcpyHostToDevice, x->stream));
+    VQ_TRY(search_dispatch(x, x->d_q, nq, k, mode, x->d_ids, x->d_out));
+    VQ_HIP(hipMemcpyAsync(ids, x->d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, x->stream));
+    VQ_HIP(hipMemcpyAsync(dist, x->d_out, (size_t)nq * k * 4, hipMemcpyDeviceToHost, x->stream));
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
+int vq_index_synchronize(vq_index* x) {
+    VQ_CHECK(x, "vq_index_synchronize: null handle");
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
+int vq_index_set_stream(vq_index* x, void* hip_stream) {
+    VQ_CHECK(x, "vq_index_set_stream: null handle");
+    std::lock_guard<std::mutex> lk(x->mu);
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    x->stream = hip_stream ? (hipStream_t)hip_stream : x->own_stream;
+    return 0;
+}
+
+int vq_index_export(vq_index* x, float* rows) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && (x->size == 0 || rows), "vq_index_export: null argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->size == 0) return 0;
+    VQ_HIP(hipMemcpyAsync(rows, x->rows, (size_t)x->size * x->dim * 4, hipMemcpyDeviceToHost, x->stream));
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
+int vq_index_profile_begin(vq_index* x) {
+    VQ_CHECK(x, "vq_index_profile_begin: null handle");
+    std::lock_guard<std::mutex> lk(x->mu);
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    for (auto& ev : x->events) { x->pool.push_back(ev.a); x->pool.push_back(ev.b); }
+    x->events.clear();
+    x->profiling = true;
+    return 0;
+}
+
+int vq_index_profile_end(vq_index* x, float* ms, int* launches) {
+    VQ_CHECK(x && ms && launches, "vq_index_profile_end: null argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    x->profiling = false;
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    for (int i = 0; i < VQ_IDX_NCLASS; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    for (auto& ev : x->events) {
+        float t = 0.f;
+        VQ_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
+        ms[ev.cls] += t; launches[ev.cls] += 1;
+        x->pool.push_back(ev.a); x->pool.push_back(ev.b);
+    }
+    x->events.clear();
+    return 0;
+}
+
+const char* vq_index_profile_class_name(int cls) {
+    return (cls >= 0 && cls < VQ_IDX_NCLASS) ? kIdxClassNames[cls] : "";
+}
+
+int vq_index_last_search_stats(vq_index* x, int64_t* stats) {
+    VQ_CHECK(x && stats, "vq_index_last_search_stats: null argument");
+    for (int i = 0; i < 3; ++i) stats[i] = x->stats[i];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""Thin owner of a ``vq_encoder`` handle (include/vq_amd.h): weights in, uint8
+frames in, L2-normalised fp32 embeddings out.  Used by
+core.feature_extractor.FeatureExtractor, bench.py and the tests.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_float, c_int, c_uint8, c_void_p
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .weights import VitConfig, weight_names
+
+
+class VitEncoder:
+    def __init__(self, cfg: VitConfig, weights: Dict[str, np.ndarray], max_batch: int = 256,
+                 device: Optional[int] = None):
+        self.cfg = cfg
+        self.max_batch = int(max_batch)
+        self.device = _lib.init(device)
+        lib = _lib.load()
+        names = weight_names(cfg)
+        self._keep = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in names]
+        ptrs = (POINTER(c_float) * len(names))(*[_lib.fptr(a) for a in self._keep])
+        ccfg = _lib.VitConfigC(cfg.image_size, cfg.patch_size, cfg.hidden, cfg.mlp, cfg.layers, cfg.heads,
+                               cfg.proj_dim, cfg.ln_eps)
+        h = c_void_p()
+        _lib.check(lib.vq_encoder_create(ctypes.byref(ccfg), ptrs, len(names), self.max_batch, ctypes.byref(h)))
+        self._h = h
+        self._keep = None          # the library has its own device copies now
+        self.output_dim = cfg.proj_dim
+
+    # -- host buffers ---------------------------------------------------------
+    def encode(self, frames: np.ndarray, swap_rb: bool = True) -> np.ndarray:
+        """uint8 [n,S,S,3] → fp32 [n,proj_dim] (synchronous)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        s = self.cfg.image_size
+        if frames.ndim != 4 or frames.shape[1:] != (s, s, 3):
+            raise ValueError(f"frames must be [n,{s},{s},3] uint8, got {frames.shape}")
+        n = frames.shape[0]
+        out = np.empty((n, self.cfg.proj_dim), dtype=np.float32)
+        if n:
+            _lib.check(_lib.load().vq_encoder_encode_u8(self._h, frames.ctypes.data_as(POINTER(c_uint8)), n,
+                                                        int(bool(swap_rb)), _lib.fptr(out)))
+        return out
+
+    # -- device buffers (pointers, e.g. torch.Tensor.data_ptr()) ----------------
+    def encode_device(self, d_frames: int, n: int, d_out_f32: int, d_out_f16: int = 0, swap_rb: bool = True) -> None:
+        """Asynchronous on the encoder's stream; call synchronize() before reading."""
+        _lib.check(_lib.load().vq_encoder_encode_u8_device(self._h, c_void_p(d_frames), int(n), int(bool(swap_rb)),
+                                                           c_void_p(d_out_f32), c_void_p(d_out_f16 or None)))
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.load().vq_encoder_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int) -> None:
+        """Launch on a caller-owned stream (e.g. torch.cuda.current_stream().cuda_stream); 0 = own stream."""
+        _lib.check(_lib.load().vq_encoder_set_stream(self._h, c_void_p(hip_stream or None)))
+
+    # -- measurement / test hooks ---------------------------------------------
+    def profile_begin(self) -> None:
+        _lib.check(_lib.load().vq_encoder_profile_begin(self._h))
+
+    def profile_end(self) -> Dict[str, dict]:
+        lib = _lib.load()
+        ms = (c_float * _lib.ENC_NCLASS)()
+        cnt = (c_int * _lib.ENC_NCLASS)()
+        _lib.check(lib.vq_encoder_profile_end(self._h, ms, cnt))
+        return {lib.vq_encoder_profile_class_name(i).decode(): {"ms": float(ms[i]), "launches": int(cnt[i])}
+                for i in range(_lib.ENC_NCLASS)}
+
+    def debug_set_layers(self, layers: int) -> None:
+        _lib.check(_lib.load().vq_encoder_debug_set_layers(self._h, int(layers)))
+
+    def debug_read(self, name: str, rows: int) -> np.ndarray:
+        cols = {"x": self.cfg.hidden, "h": self.cfg.hidden, "qkv": 3 * self.cfg.hidden, "att": self.cfg.hidden,
+                "mlp": self.cfg.mlp}[name]
+        out = np.empty((rows, cols), dtype=np.float32)
+        _lib.check(_lib.load().vq_encoder_debug_read(self._h, name.encode(), int(rows), _lib.fptr(out)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.load().vq_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_gemm(a: np.ndarray, w: np.ndarray, use_f16: bool = False) -> np.ndarray:
+    """C = A @ W.T through the production MFMA mainloop (unit-test hook)."""
+    _lib.init()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    m, k = a.shape
+    n = w.shape[0]
+    c = np.empty((m, n), dtype=np.float32)
+    _lib.check(_lib.load().vq_debug_gemm(_lib.fptr(a), _lib.fptr(w), m, n, k, int(use_f16), _lib.fptr(c)))
+    return c

@@ -1,0 +1,343 @@
+"""Drop-in for the reference's ``indexes.hnsw`` module (reference
+src/indexes/hnsw.py): ``HNSWIndex`` / ``OptimizedHNSWIndex`` with the same
+constructor, methods, result dicts and pickle layout — but ``search`` is an
+EXACT scan of a device-resident matrix in libvq_amd (no graph walk), i.e. what
+the reference itself returns once ``ef_search >= N``:
+
+    distance_i = fp32(1 - fp32(dot(x_i, q))),  k smallest by (distance, id).
+
+The graph parameters (M, ef_construction, ef_search, max_M,
+level_generation_factor) are accepted and echoed by ``get_stats`` but have no
+effect.  There is no CPU path: without the library or a gfx950 device
+construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import math
+import os
+import pickle
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
+from typing import Dict, Hashable, List, Optional, Sequence
+
+import numpy as np
+
+from video_quierer_amd import _lib
+
+MODE_AUTO, MODE_EXACT, MODE_FP16 = 0, 1, 2
+
+
+class HNSWIndex:
+    def __init__(self, dimension: int = 512, M: int = 16, ef_construction: int = 200, ef_search: int = 50,
+                 max_M: int = 16, level_generation_factor: float = 1.0 / math.log(2.0), num_threads: int = 4,
+                 device: Optional[int] = None):
+        # reference :25-57
+        self.dimension = dimension
+        self.M = M
+        self.max_M = max_M
+        self.ef_construction = ef_construction
+        self.ef_search = ef_search
+        self.level_generation_factor = level_generation_factor
+        self.num_threads = num_threads
+
+        self.entry_point = None
+        self.element_count = 0
+        self.lock = threading.RLock()
+        self.thread_pool = ThreadPoolExecutor(max_workers=num_threads)
+        self.build_time = 0
+        self.search_times: List[float] = []
+        self.search_mode = MODE_AUTO
+
+        self._ids: List[Hashable] = []            # row -> caller id
+        self._row_of: Dict[Hashable, int] = {}    # caller id -> row
+        self._identity = True                     # ids are exactly 0..n-1 in row order
+        _lib.init(device)
+        h = c_void_p()
+        _lib.check(_lib.load().vq_index_create(int(dimension), ctypes.byref(h)))
+        self._h = h
+
+    # -- reference-shaped views of the state (hnsw.py:44-49) ---------------------
+    @property
+    def data(self) -> Dict[Hashable, np.ndarray]:
+        rows = self._export()
+        return {i: rows[r] for r, i in enumerate(self._ids)}
+
+    @property
+    def levels(self) -> Dict[Hashable, int]:
+        return {i: 0 for i in self._ids}          # exact index: a single flat level
+
+    @property
+    def graph(self) -> dict:
+        return {0: {i: set() for i in self._ids}}
+
+    def _export(self) -> np.ndarray:
+        n = len(self._ids)
+        rows = np.empty((n, self.dimension), dtype=np.float32)
+        if n:
+            _lib.check(_lib.load().vq_index_export(self._h, _lib.fptr(rows)))
+        return rows
+
+    # -- build --------------------------------------------------------------------
+    @staticmethod
+    def _unit(vector) -> np.ndarray:
+        v = np.asarray(vector)
+        return (v / np.linalg.norm(v)).astype(np.float32, copy=False)     # hnsw.py:157 (no zero guard)
+
+    def add(self, vector: np.ndarray, node_id: Hashable) -> None:
+        self.add_batch([vector], [node_id])                               # reference :150-229
+
+    def add_batch(self, vectors: Sequence[np.ndarray], node_ids: Sequence[Hashable]) -> None:
+        """Reference :231-236 (a per-vector loop there); here one device append."""
+        node_ids = list(node_ids)
+        n = min(len(vectors), len(node_ids))                              # zip semantics
+        if n == 0:
+            return
+        t0 = time.time()
+        with self.lock:
+            vs = np.asarray(vectors[:n] if not isinstance(vectors, np.ndarray) else vectors[:n])
+            if vs.ndim != 2 or vs.shape[1] != self.dimension:
+                raise ValueError(f"vectors must be [n,{self.dimension}], got {vs.shape}")
+            # row-wise `v / np.linalg.norm(v)` exactly as the reference computes it (:157)
+            unit = np.stack([self._unit(v) for v in vs])
+            unit = np.ascontiguousarray(unit, dtype=np.float32)
+            fresh_rows, fresh_ids = [], []
+            seen_now: Dict[Hashable, int] = {}
+            for j, nid in enumerate(node_ids[:n]):
+                if nid in self._row_of:
+                    self._overwrite(self._row_of[nid], unit[j])
+                elif nid in seen_now:                                    # later duplicate wins (dict semantics)
+                    fresh_rows[seen_now[nid]] = j
+                else:
+                    seen_now[nid] = len(fresh_rows)
+                    fresh_rows.append(j)
+                    fresh_ids.append(nid)
+                self.element_count += 1                                   # reference counts every add (:229)
+            if fresh_rows:
+                block = unit if len(fresh_rows) == n else np.ascontiguousarray(unit[fresh_rows])
+                _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(block), len(fresh_rows), 0))
+                base = len(self._ids)
+                for j, nid in enumerate(fresh_ids):
+                    self._row_of[nid] = base + j
+                    if self._identity and not (isinstance(nid, (int, np.integer)) and int(nid) == base + j):
+                        self._identity = False
+                self._ids.extend(fresh_ids)
+            if self.entry_point is None and self._ids:
+                self.entry_point = self._ids[0]
+        self.build_time += time.time() - t0
+
+    def add_device(self, d_rows: int, n: int, node_ids: Sequence[Hashable], normalize: bool = True) -> None:
+        """Append n device-resident fp32 rows (e.g. straight from the encoder) without a host round trip."""
+        node_ids = list(node_ids)
+        if len(node_ids) != n:
+            raise ValueError("node_ids must have n entries")
+        with self.lock:
+            if any(i in self._row_of for i in node_ids) or len(set(node_ids)) != n:
+                raise ValueError("add_device: ids must be new and unique")
+            _lib.check(_lib.load().vq_index_add_device(self._h, c_void_p(d_rows), n, int(bool(normalize))))
+            base = len(self._ids)
+            for j, nid in enumerate(node_ids):
+                self._row_of[nid] = base + j
+                if self._identity and not (isinstance(nid, (int, np.integer)) and int(nid) == base + j):
+                    self._identity = False
+            self._ids.extend(node_ids)
+            self.element_count += n
+            if self.entry_point is None and self._ids:
+                self.entry_point = self._ids[0]
+
+    def _overwrite(self, row: int, unit_vec: np.ndarray) -> None:
+        # re-adding an id replaces its vector (dict assignment in the reference, :160); rare → rebuild
+        rows = self._export()
+        rows[row] = unit_vec
+        lib = _lib.load()
+        _lib.check(lib.vq_index_clear(self._h))
+        _lib.check(lib.vq_index_add(self._h, _lib.fptr(rows), rows.shape[0], 0))
+
+    # -- query --------------------------------------------------------------------
+    def _raw_search(self, unit_queries: np.ndarray, k: int):
+        nq = unit_queries.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dist = np.empty((nq, k), dtype=np.float32)
+        _lib.check(_lib.load().vq_index_search(self._h, _lib.fptr(unit_queries), nq, k, int(self.search_mode),
+                                               ids.ctypes.data_as(POINTER(c_int32)), _lib.fptr(dist)))
+        return ids, dist
+
+    def _search_many(self, queries: Sequence[np.ndarray], k: int) -> List[List[Dict]]:
+        n = len(self._ids)
+        unit = np.ascontiguousarray(np.stack([self._unit(q) for q in queries]), dtype=np.float32)
+        if unit.shape[1] != self.dimension:
+            raise ValueError(f"query dimension {unit.shape[1]} != index dimension {self.dimension}")
+        kk = min(k, n)
+        if self._identity:
+            ids, dist = self._raw_search(unit, kk)
+            return [[{"id": int(i), "distance": d, "score": np.float32(1.0) - d} for i, d in zip(ri, rd) if i >= 0]
+                    for ri, rd in zip(ids, dist)]
+        # arbitrary ids: the library orders ties by row; the reference orders them by id
+        # (hnsw.py:269/518).  Over-fetch until no tie group is cut at rank k, then re-sort.
+        fetch = min(n, kk + 8)
+        while True:
+            ids, dist = self._raw_search(unit, fetch)
+            cut = fetch < n and np.any(dist[:, kk - 1] == dist[:, fetch - 1])
+            if not cut:
+                break
+            fetch = min(n, fetch * 2)
+        out = []
+        for ri, rd in zip(ids, dist):
+            cand = sorted(((d, self._ids[i]) for i, d in zip(ri, rd) if i >= 0))[:kk]
+            out.append([{"id": i, "distance": d, "score": np.float32(1.0) - d} for d, i in cand])
+        return out
+
+    def search(self, query: np.ndarray, k: int = 5) -> List[Dict]:
+        """Reference :238-280 / :488-528."""
+        if self.entry_point is None or self.element_count == 0:
+            return []
+        t0 = time.time()
+        with self.lock:
+            res = self._search_many([query], k)[0]
+        self.search_times.append((time.time() - t0) * 1000)
+        return res
+
+    def search_batch(self, queries: List[np.ndarray], k: int = 5) -> List[List[Dict]]:
+        """Reference :282-300 (a thread fan-out serialised by the index lock); here one batched scan."""
+        if len(queries) == 0:
+            return []
+        if self.entry_point is None or self.element_count == 0:
+            return [[] for _ in queries]
+        t0 = time.time()
+        with self.lock:
+            res = self._search_many(queries, k)
+        per = (time.time() - t0) * 1000 / len(queries)
+        self.search_times.extend([per] * len(queries))
+        return res
+
+    def search_device(self, d_queries: int, nq: int, k: int, d_ids: int, d_dist: int, mode: Optional[int] = None) -> None:
+        """Device pointers in/out (unit fp32 queries; int32 row ids; fp32 distances); asynchronous."""
+        with self.lock:
+            _lib.check(_lib.load().vq_index_search_device(self._h, c_void_p(d_queries), int(nq), int(k),
+                                                          int(self.search_mode if mode is None else mode),
+                                                          c_void_p(d_ids), c_void_p(d_dist)))
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.load().vq_index_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int) -> None:
+        _lib.check(_lib.load().vq_index_set_stream(self._h, c_void_p(hip_stream or None)))
+
+    def size(self) -> int:
+        return self.element_count                                          # reference :302-304
+
+    # -- persistence (reference :306-380: pickle + sha256 sidecar) ------------------
+    def save(self, filepath: str) -> None:
+        with self.lock:
+            save_data = {
+                "dimension": self.dimension, "M": self.M, "max_M": self.max_M,
+                "ef_construction": self.ef_construction, "ef_search": self.ef_search,
+                "level_generation_factor": self.level_generation_factor,
+                "data": self.data, "levels": self.levels, "graph": self.graph,
+                "entry_point": self.entry_point, "element_count": self.element_count,
+                "exact_index": True,     # extra key: no navigable graph in this file
+            }
+            d = os.path.dirname(filepath)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            with open(filepath, "wb") as f:
+                pickle.dump(save_data, f, protocol=pickle.HIGHEST_PROTOCOL)
+            with open(filepath, "rb") as f:
+                checksum = hashlib.sha256(f.read()).hexdigest()
+            with open(filepath + ".sha256", "w") as f:
+                f.write(checksum)
+
+    def load(self, filepath: str) -> None:
+        try:
+            with open(filepath, "rb") as f:
+                current = hashlib.sha256(f.read()).hexdigest()
+            with open(filepath + ".sha256", "r") as f:
+                expected = f.read().strip()
+            if current != expected:
+                raise ValueError("Index file corrupted (checksum mismatch)")
+        except FileNotFoundError:
+            print("Warning: No checksum file found, skipping verification")
+        with open(filepath, "rb") as f:
+            s = pickle.load(f)
+        with self.lock:
+            if s["dimension"] != self.dimension:
+                lib = _lib.load()
+                lib.vq_index_destroy(self._h)
+                h = c_void_p()
+                _lib.check(lib.vq_index_create(int(s["dimension"]), ctypes.byref(h)))
+                self._h = h
+            else:
+                _lib.check(_lib.load().vq_index_clear(self._h))
+            self.dimension = s["dimension"]
+            self.M, self.max_M = s["M"], s["max_M"]
+            self.ef_construction, self.ef_search = s["ef_construction"], s["ef_search"]
+            self.level_generation_factor = s["level_generation_factor"]
+            self._ids, self._row_of, self._identity = [], {}, True
+            ids = list(s["data"].keys())
+            if ids:
+                rows = np.ascontiguousarray(np.stack([np.asarray(s["data"][i], dtype=np.float32) for i in ids]))
+                _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(rows), len(ids), 0))   # stored rows are already unit
+                for r, nid in enumerate(ids):
+                    self._row_of[nid] = r
+                    if self._identity and not (isinstance(nid, (int, np.integer)) and int(nid) == r):
+                        self._identity = False
+                self._ids = ids
+            self.entry_point = s["entry_point"]
+            self.element_count = s["element_count"]
+
+    # -- stats (reference :382-402) ---------------------------------------------------
+    def get_stats(self) -> Dict:
+        if self.search_times:
+            avg = sum(self.search_times) / len(self.search_times)
+            p95 = np.percentile(self.search_times, 95)
+        else:
+            avg = p95 = 0
+        return {
+            "element_count": self.element_count,
+            "entry_point_level": 0,
+            "avg_search_time_ms": avg,
+            "p95_search_time_ms": p95,
+            "total_searches": len(self.search_times),
+            "dimension": self.dimension,
+            "M": self.M,
+            "ef_search": self.ef_search,
+        }
+
+    def last_search_stats(self) -> Dict[str, int]:
+        st = (c_int64 * 3)()
+        _lib.check(_lib.load().vq_index_last_search_stats(self._h, st))
+        return {"verified": int(st[0]), "rescanned": int(st[1]), "exact_fallback": int(st[2])}
+
+    def profile_begin(self) -> None:
+        _lib.check(_lib.load().vq_index_profile_begin(self._h))
+
+    def profile_end(self) -> Dict[str, dict]:
+        lib = _lib.load()
+        ms = (c_float * _lib.IDX_NCLASS)()
+        cnt = (ctypes.c_int * _lib.IDX_NCLASS)()
+        _lib.check(lib.vq_index_profile_end(self._h, ms, cnt))
+        return {lib.vq_index_profile_class_name(i).decode(): {"ms": float(ms[i]), "launches": int(cnt[i])}
+                for i in range(_lib.IDX_NCLASS)}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.load().vq_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OptimizedHNSWIndex(HNSWIndex):
+    """Reference :405-528.  ``use_numpy_optimization`` is accepted for signature
+    compatibility; both classes run the same device scan."""
+
+    def __init__(self, *args, use_numpy_optimization=True, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_numpy_optimization = use_numpy_optimization
