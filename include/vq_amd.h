@@ -100,9 +100,11 @@ const char* vq_encoder_profile_class_name(int cls);
 int vq_encoder_debug_set_layers(vq_encoder* enc, int layers);
 int vq_encoder_debug_read(vq_encoder* enc, const char* name, int rows, float* out);
 
-/* C[M][N] = A[M][K] * W[N][K]^T through the production MFMA mainloop (bf16 or
- * fp16 inputs rounded from the given fp32, fp32 accumulate) — unit-test hook. */
-int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int use_f16, float* C);
+/* C[M][N] = A[M][K] * W[N][K]^T through the production MFMA mainloops (inputs
+ * rounded from the given fp32, fp32 accumulate) — unit-test hook.
+ * flags: bit 0 = fp16 inputs (else bf16); bits 1-2 = kernel (0 auto, 1 = 128x128
+ * two-phase, 2 = 256x256 phased). */
+int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C);
 
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;

@@ -17,31 +17,41 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-def test_gemm_mfma_integer_exact(gpu_lib):
+@pytest.mark.parametrize("kernel", [1, 2])          # 1 = 128x128 two-phase, 2 = 256x256 phased
+def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(0)
-    m, n, k = 256, 256, 192
+    m, n, k = 512, 256, 384
     a = np.zeros((m, k), np.float32)
     a[np.arange(m), np.arange(m) % k] = 1.0                  # row i picks column i % k  ("A = I" check)
     w = rng.integers(-8, 9, (n, k)).astype(np.float32)       # asymmetric W catches a transposed C write
-    c = debug_gemm(a, w)
+    c = debug_gemm(a, w, kernel=kernel)
     assert np.array_equal(c, a @ w.T)
     a = rng.integers(-4, 5, (m, k)).astype(np.float32)
     for f16 in (False, True):
-        assert np.array_equal(debug_gemm(a, w, use_f16=f16), a @ w.T)   # small ints: exact in bf16/fp16/fp32-acc
+        assert np.array_equal(debug_gemm(a, w, use_f16=f16, kernel=kernel), a @ w.T)   # small ints: exact
+    # many k-tiles and several workgroups per XCD: exercises the steady-state pipeline and the tile remap
+    m, n, k = 1024, 768, 3072
+    a = rng.integers(-2, 3, (m, k)).astype(np.float32)
+    w = rng.integers(-2, 3, (n, k)).astype(np.float32)
+    assert np.array_equal(debug_gemm(a, w, kernel=kernel), a @ w.T)
 
 
-def test_gemm_mfma_random(gpu_lib):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_gemm_mfma_random(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(1)
-    m, n, k = 384, 128, 3072
+    m, n, k = 512, 256, 3072
     a = rng.standard_normal((m, k)).astype(np.float32)
     w = rng.standard_normal((n, k)).astype(np.float32)
     ab = torch.from_numpy(a).bfloat16().float().numpy()
     wb = torch.from_numpy(w).bfloat16().float().numpy()
     ref = ab.astype(np.float64) @ wb.astype(np.float64).T
-    c = debug_gemm(a, w)
+    c = debug_gemm(a, w, kernel=kernel)
     assert np.abs(c - ref).max() <= 2e-3 * np.sqrt(k)        # fp32 accumulation of exact bf16 products
+    # repeated launches give identical bits (no race between the DMA ring and the fragment reads)
+    for _ in range(5):
+        assert np.array_equal(debug_gemm(a, w, kernel=kernel), c)
 
 
 # ------------------------------------------------------------------ encoder

@@ -1,0 +1,221 @@
+// 256x256x64 "phased" bf16/fp16 TN GEMM for gfx950 (second-generation mainloop).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]      (same contract and epilogue functors as gemm_mfma.h)
+//
+// Why a second kernel: at 128x128 a tile needs 64 B of L2->LDS traffic per MFMA
+// cycle per CU, i.e. the whole chip would need ~34 TB/s of L2 bandwidth at full
+// MFMA rate; 256x256 halves that and cuts LDS fragment reads per MFMA by 25 %.
+//
+// Geometry: 512 threads = 8 waves as 2 (m) x 4 (n); a wave owns 128 x 64 of C =
+// 8 x 4 MFMA 16x16x32 tiles (128 accumulator VGPRs).  LDS = 2 K-tile buffers x
+// {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255} x 16 KiB = 128 KiB,
+// every half-tile a lane-linear LDS-DMA image with the 16-byte chunk XOR-swizzled
+// by (row>>1)&7 on the source address and on the fragment read (conflict-free
+// ds_read_b128).
+//
+// Schedule: each K-tile is 4 phases; a phase = {ds_read the register sub-tile it
+// needs, issue ONE half-tile of LDS-DMA prefetch, s_barrier, 16 MFMAs (one
+// 64 x 32 quadrant x K=64), s_barrier}.  Quadrant order (0,0) (0,1) (1,1) (1,0)
+// re-reads only one operand sub-tile per phase (12+4+8+4 = 28 ds_read_b128 per 64
+// MFMAs).  Prefetch for K-tile t+1 is issued during tile t (A half 1, W half 0,
+// W half 1 in phases 1-3) and its A half 0 already in phase 4 of tile t-1 into the
+// buffer whose A halves were last read in phase 3.  The only VMEM wait in the loop
+// is a COUNTED s_waitcnt vmcnt(2) at the end of phase 4 (one half-tile stays in
+// flight across the tile boundary); barriers are raw s_barrier, never
+// __syncthreads() (which would drain the DMA queue).
+//
+// Requirements: M % 256 == 0, N % 256 == 0, K % 128 == 0.
+#pragma once
+#include "vq_common.h"
+#include "gemm_mfma.h"
+
+namespace vq {
+
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64, G2_THREADS = 512;
+constexpr int G2_HALF = 128 * G2_BK * 2;          // 16 KiB: 128 rows x 64 k
+constexpr int G2_BUF = 4 * G2_HALF;               // 64 KiB per K-tile buffer
+constexpr int G2_LDS_BYTES = 2 * G2_BUF;          // 128 KiB
+
+template <bool IS_F16, class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
+                       const uint16_t* __restrict__ W, int ldw,
+                       int K, int tiles_n, Epi epi) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * G2_BM;
+    const int n0 = (wg % tiles_n) * G2_BN;
+
+    // ---- LDS-DMA source pointers: wave w fills 1-KiB pieces 2w, 2w+1 of a half-tile ----
+    const int srow = lane >> 3, sslot = lane & 7;
+    const uint16_t* a_src[2];
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + srow;            // row inside the 128-row half-tile
+        const int chunk = sslot ^ ((row >> 1) & 7);
+        a_src[i] = A + (size_t)(m0 + row) * lda + chunk * 8;
+        w_src[i] = W + (size_t)(n0 + row) * ldw + chunk * 8;
+    }
+    const size_t a_half = (size_t)128 * lda, w_half = (size_t)128 * ldw;
+    const int piece_off = wave * 2048;                         // pieces 2w,2w+1 are contiguous
+
+    // which: 0 = A half 0, 1 = A half 1, 2 = W half 0, 3 = W half 1
+    auto stage = [&](int buf, int which, int kt) {
+        char* dst = smem + buf * G2_BUF + which * G2_HALF + piece_off;
+        const int koff = kt * G2_BK;
+        if (which < 2) {
+            const size_t ho = which ? a_half : 0;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[0] + ho + koff), (lds_void_t*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[1] + ho + koff), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        } else {
+            const size_t ho = (which & 1) ? w_half : 0;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[0] + ho + koff), (lds_void_t*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[1] + ho + koff), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;                                     // + mi*2048
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;   // + ni*2048
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag af[4][2], wf[2][2];
+
+    const int nk = K / G2_BK;
+
+    auto load_a = [&](const char* buf, int hm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf, int hn) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
+    };
+    auto mfma_quadrant = [&](int hm, int hn) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // One K-tile = 4 phases.  BUF is a compile-time constant (the loop body is unrolled by 2).
+    auto tile = [&](int kt, int bufi) {
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+        // phase 1: quadrant (0,0)
+        load_a(buf, 0); load_w(buf, 0);
+        if (next) stage(bufi ^ 1, 1, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 0);
+        barrier();
+        // phase 2: quadrant (0,1)
+        load_w(buf, 1);
+        if (next) stage(bufi ^ 1, 2, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 1);
+        barrier();
+        // phase 3: quadrant (1,1)
+        load_a(buf, 1);
+        if (next) stage(bufi ^ 1, 3, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 1);
+        barrier();
+        // phase 4: quadrant (1,0); this buffer's A halves are dead -> start tile kt+2's A half 0
+        load_w(buf, 0);
+        if (next2) stage(bufi, 0, kt + 2);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 0);
+        if (next2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // tile kt+1 landed; kt+2's first half in flight
+        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier();
+    };
+
+    // ---- prologue: tile 0 complete, tile 1's A half 0 in flight ----
+    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
+    if (nk > 1) { stage(1, 0, 1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else        { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    barrier();
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile(kt, 0);
+        tile(kt + 1, 1);
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3] ----
+    const int m_base = m0 + wr * 128 + frow;
+    const int n_base = n0 + wc * 64 + fgrp * 4;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                             int M, int N, int K, const Epi& epi) {
+    VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
+             "gemm_tn256: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn256: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    static bool attr_set = false;       // per instantiation
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_kernel<IS_F16, Epi>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
+    hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
+                       A, lda, W, ldw, K, tiles_n, epi);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// Dispatch: the phased 256x256 kernel when the problem tiles by it and yields enough
+// workgroups to occupy the chip, else the 128x128 kernel.
+template <bool IS_F16, class Epi>
+static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                            int M, int N, int K, const Epi& epi, int force = 0) {
+    const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
+    const bool want256 = force == 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
+    if (fits256 && want256 && force != 1) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+}
+
+}  // namespace vq

@@ -3,6 +3,7 @@
 #include "../../include/vq_amd.h"
 #include "vq_common.h"
 #include "gemm_mfma.h"
+#include "gemm_mfma256.h"
 
 #include <cstring>
 #include <vector>
@@ -76,9 +77,10 @@ int vq_init(int device_ordinal) {
     return 0;
 }
 
-int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int use_f16, float* C) {
+int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C) {
     VQ_TRY(require_init());
     VQ_CHECK(A && W && C, "vq_debug_gemm: null argument");
+    const int use_f16 = flags & 1, force = (flags >> 1) & 3;    // force: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel
     std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
     for (size_t i = 0; i < a16.size(); ++i)
         a16[i] = use_f16 ? __builtin_bit_cast(uint16_t, (_Float16)A[i]) : f32_to_bf16_rne(A[i]);
@@ -91,8 +93,8 @@ int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int use_f
     VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4));
     VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
     VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
-    int rc = use_f16 ? launch_gemm_tn<true>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N})
-                     : launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+    int rc = use_f16 ? launch_gemm_auto<true>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, force)
+                     : launch_gemm_auto<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, force);
     if (rc == 0) {
         hipError_t e = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(VQ_ERR_HIP, "vq_debug_gemm: copy back failed: %s", hipGetErrorString(e));

@@ -5,10 +5,12 @@
 #include "../../include/vq_amd.h"
 #include "vq_common.h"
 #include "gemm_mfma.h"
+#include "gemm_mfma256.h"
 #include "encoder_kernels.h"
 
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -58,6 +60,7 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     int run_layers = -1;
     int last_n = 0;
+    int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles
     // profiling
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -118,9 +121,15 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     hipStream_t st = e->stream;
     const int H = c.hidden, T = e->tokens;
     const int rows = n * T;
-    const int rows_gemm = (int)round_up(rows, GEMM_BM);
+    // GEMM row counts are padded (the buffers are): to 256 when that adds < 6 % work, so the phased
+    // 256x256 kernel applies; small batches keep 128-row granularity
+    auto pad_rows = [](int r) {
+        const int r256 = (int)round_up(r, G2_BM), r128 = (int)round_up(r, GEMM_BM);
+        return (r256 - r128) * 16 <= r128 ? r256 : r128;
+    };
+    const int rows_gemm = pad_rows(rows);
     const int prows = n * e->patches;
-    const int prows_gemm = (int)round_up(prows, GEMM_BM);
+    const int prows_gemm = pad_rows(prows);
 
     {   // E1/E2 + im2col: uint8 frames -> bf16 patch rows (aliases the MLP buffer)
         Prof p(e, C_PATCHIFY);
@@ -131,8 +140,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     }
     {   // E3: patch-embedding conv as a GEMM, epilogue scatters into token rows + position embedding
         Prof p(e, C_GEMM_PATCH);
-        VQ_TRY((launch_gemm_tn<false>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
-                                      EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows})));
+        VQ_TRY((launch_gemm_auto<false>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
+                                        EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force)));
     }
     const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
     {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
@@ -150,8 +159,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
             Prof p(e, C_GEMM_QKV);
-            VQ_TRY((launch_gemm_tn<false>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
-                                          EpiBiasBf16{e->qkv, 3 * H, L.b_qkv})));
+            VQ_TRY((launch_gemm_auto<false>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
+                                            EpiBiasBf16{e->qkv, 3 * H, L.b_qkv}, e->gemm_force)));
         }
         {
             Prof p(e, C_ATTENTION);
@@ -160,8 +169,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {
             Prof p(e, C_GEMM_OUT);
-            VQ_TRY((launch_gemm_tn<false>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
-                                          EpiBiasResidualF32{e->x, H, L.b_out})));
+            VQ_TRY((launch_gemm_auto<false>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
+                                            EpiBiasResidualF32{e->x, H, L.b_out}, e->gemm_force)));
         }
         {
             Prof p(e, C_LAYERNORM);
@@ -170,13 +179,13 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // E7: fc1 + quick_gelu
             Prof p(e, C_GEMM_FC1);
-            VQ_TRY((launch_gemm_tn<false>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
-                                          EpiBiasQuickGeluBf16{e->mlp, c.mlp, L.b_fc1})));
+            VQ_TRY((launch_gemm_auto<false>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
+                                            EpiBiasQuickGeluBf16{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
         }
         {
             Prof p(e, C_GEMM_FC2);
-            VQ_TRY((launch_gemm_tn<false>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
-                                          EpiBiasResidualF32{e->x, H, L.b_fc2})));
+            VQ_TRY((launch_gemm_auto<false>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
+                                            EpiBiasResidualF32{e->x, H, L.b_fc2}, e->gemm_force)));
         }
     }
     {   // E8-E10
@@ -224,6 +233,7 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
     VQ_CHECK(patch_k == patch_k_raw, "vq_encoder_create: patch K %d must be a multiple of 64", patch_k_raw);
 
     vq_encoder* e = new vq_encoder();
+    if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
     e->rows_pad = round_up((int64_t)max_batch * tokens, 256);
     e->prow_pad = round_up((int64_t)max_batch * patches, 256);

@@ -93,13 +93,14 @@ class VitEncoder:
             pass
 
 
-def debug_gemm(a: np.ndarray, w: np.ndarray, use_f16: bool = False) -> np.ndarray:
-    """C = A @ W.T through the production MFMA mainloop (unit-test hook)."""
+def debug_gemm(a: np.ndarray, w: np.ndarray, use_f16: bool = False, kernel: int = 0) -> np.ndarray:
+    """C = A @ W.T through the production MFMA mainloops (unit-test hook).
+    kernel: 0 auto, 1 = 128x128 two-phase, 2 = 256x256 phased."""
     _lib.init()
     a = np.ascontiguousarray(a, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
     m, k = a.shape
     n = w.shape[0]
     c = np.empty((m, n), dtype=np.float32)
-    _lib.check(_lib.load().vq_debug_gemm(_lib.fptr(a), _lib.fptr(w), m, n, k, int(use_f16), _lib.fptr(c)))
+    _lib.check(_lib.load().vq_debug_gemm(_lib.fptr(a), _lib.fptr(w), m, n, k, int(bool(use_f16)) | (int(kernel) << 1), _lib.fptr(c)))
     return c
