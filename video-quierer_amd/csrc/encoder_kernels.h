@@ -338,43 +338,63 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 // ============================ pooling head ===================================
 // CLS token -> post_layernorm -> visual_projection (fp32 weights, no bias) ->
 // L2 normalise (x / max(||x||, 1e-12), F.normalize)                 (E8-E10)
-// One 256-thread workgroup per image; each wave produces proj_dim/4 outputs,
-// every output a lane-split dot over `hidden` + wave reduction.
+// One 256-thread workgroup per POOL_IMGS images: every projection row is read once
+// per workgroup and dotted against all its images (lane-split over `hidden`, wave
+// reduction), so the 1.5 MB weight is re-read B/POOL_IMGS times instead of B times.
+constexpr int POOL_IMGS = 4;
 template <int NV>
 __global__ __launch_bounds__(256)
 void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ g,
                          const float* __restrict__ b, const float* __restrict__ wproj,
                          float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
-                         int tokens, int proj_dim, float eps) {
+                         int n_images, int tokens, int proj_dim, float eps) {
     constexpr int H = NV * 256;
-    __shared__ float feat[2048];
-    __shared__ float red[4];
+    __shared__ float feat[POOL_IMGS][2048];
+    __shared__ float red[POOL_IMGS][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int img = blockIdx.x;
-    float4 v[NV];
+    const int img0 = blockIdx.x * POOL_IMGS;
+    float4 v[POOL_IMGS][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
-    ln_row<NV>(v, g, b, lane, eps, H);     // every wave normalises the same row (cheap, avoids a broadcast)
-    float ss = 0.f;
+    for (int im = 0; im < POOL_IMGS; ++im) {
+        const int img = min(img0 + im, n_images - 1);          // tail workgroup: duplicate the last image
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[im][i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
+        ln_row<NV>(v[im], g, b, lane, eps, H);                   // every wave normalises the same rows
+    }
+    float ss[POOL_IMGS];
+#pragma unroll
+    for (int im = 0; im < POOL_IMGS; ++im) ss[im] = 0.f;
     for (int o = wave; o < proj_dim; o += 4) {
         const float* wr = wproj + (size_t)o * H;
-        float acc = 0.f;
+        float4 w[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float4 w = *(const float4*)(wr + (i * 64 + lane) * 4);
-            acc += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+        for (int i = 0; i < NV; ++i) w[i] = *(const float4*)(wr + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int im = 0; im < POOL_IMGS; ++im) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                acc += (v[im][i].x * w[i].x + v[im][i].y * w[i].y) + (v[im][i].z * w[i].z + v[im][i].w * w[i].w);
+            acc = wave_sum(acc);
+            if (lane == 0) feat[im][o] = acc;
+            ss[im] += acc * acc;                                 // identical in every lane
         }
-        acc = wave_sum(acc);
-        if (lane == 0) feat[o] = acc;
-        ss += acc * acc;                    // identical in every lane
     }
-    if (lane == 0) red[wave] = ss;
+    if (lane == 0) {
+#pragma unroll
+        for (int im = 0; im < POOL_IMGS; ++im) red[im][wave] = ss[im];
+    }
     __syncthreads();
-    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
-    for (int o = threadIdx.x; o < proj_dim; o += 256) {
-        const float e = feat[o] / nrm;
-        out_f32[(size_t)img * proj_dim + o] = e;
-        if (out_f16) out_f16[(size_t)img * proj_dim + o] = __builtin_bit_cast(uint16_t, (_Float16)e);
+#pragma unroll
+    for (int im = 0; im < POOL_IMGS; ++im) {
+        const int img = img0 + im;
+        if (img >= n_images) break;
+        const float nrm = fmaxf(sqrtf((red[im][0] + red[im][1]) + (red[im][2] + red[im][3])), 1e-12f);
+        for (int o = threadIdx.x; o < proj_dim; o += 256) {
+            const float e = feat[im][o] / nrm;
+            out_f32[(size_t)img * proj_dim + o] = e;
+            if (out_f16) out_f16[(size_t)img * proj_dim + o] = __builtin_bit_cast(uint16_t, (_Float16)e);
+        }
     }
 }
 

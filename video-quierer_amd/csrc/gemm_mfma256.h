@@ -15,13 +15,14 @@
 //
 // Schedule: each K-tile is 4 phases; a phase = {ds_read the register sub-tile it
 // needs, issue ONE half-tile of LDS-DMA prefetch, s_barrier, 16 MFMAs (one
-// 64 x 32 quadrant x K=64), s_barrier}.  Quadrant order (0,0) (0,1) (1,1) (1,0)
+// 64 x 32 quadrant x K=64), s_barrier}; the two wave groups (m halves) run
+// staggered by one barrier so one group's LDS reads overlap the other's MFMAs.  Quadrant order (0,0) (0,1) (1,1) (1,0)
 // re-reads only one operand sub-tile per phase (12+4+8+4 = 28 ds_read_b128 per 64
 // MFMAs).  Prefetch for K-tile t+1 is issued during tile t (A half 1, W half 0,
 // W half 1 in phases 1-3) and its A half 0 already in phase 4 of tile t-1 into the
-// buffer whose A halves were last read in phase 3.  The only VMEM wait in the loop
-// is a COUNTED s_waitcnt vmcnt(2) at the end of phase 4 (one half-tile stays in
-// flight across the tile boundary); barriers are raw s_barrier, never
+// buffer whose A half 0 was last read in phase 3.  The only VMEM wait in the loop
+// is a COUNTED s_waitcnt vmcnt(2) in the read half of phase 4 (one half-tile stays
+// in flight across the tile boundary); barriers are raw s_barrier, never
 // __syncthreads() (which would drain the DMA queue).
 //
 // Requirements: M % 256 == 0, N % 256 == 0, K % 128 == 0.
@@ -130,7 +131,19 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
         asm volatile("" ::: "memory");
     };
 
-    // One K-tile = 4 phases.  BUF is a compile-time constant (the loop body is unrolled by 2).
+    // One K-tile = 4 phases; a phase = read half {ds_reads, one half-tile of DMA} | barrier |
+    // MFMA half {16 MFMAs} | barrier.  The two wave groups (wr = 0 / 1, which share every SIMD
+    // pairwise) run STAGGERED by one barrier: while one group is in its MFMA half the other is in
+    // its read half, so LDS traffic hides under the partner's matrix work.
+    //
+    // Hazards under the stagger (group 1 is one barrier behind group 0; b(k) = k-th barrier):
+    //  RAW  the counted vmcnt that retires tile kt+1's DMA sits in the READ half of phase 4, i.e.
+    //       before b(2p) for group 0 and b(2p+1) for group 1; tile kt+1 is first read after b(2p+1)
+    //       (group 0) / b(2p+2) (group 1): every issuer's wait precedes a barrier the reader has passed.
+    //  WAR  a half-tile is re-staged >= 2 phases after its last ds_read (A half 1, W halves), except
+    //       A half 0 in phase 4 right after its last read in phase 3: A half 0 is read by group 0
+    //       only, whose phase-3 reads retire (lgkmcnt(0)) before b(2p-1), and nobody issues the
+    //       phase-4 DMA before b(2p-1).
     auto tile = [&](int kt, int bufi) {
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
@@ -155,14 +168,14 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(1, 1);
         barrier();
-        // phase 4: quadrant (1,0); this buffer's A halves are dead -> start tile kt+2's A half 0
+        // phase 4: quadrant (1,0); this buffer's A half 0 is dead -> start tile kt+2's A half 0,
+        // then retire everything older (tile kt+1 complete) with one half-tile left in flight
         load_w(buf, 0);
-        if (next2) stage(bufi, 0, kt + 2);
+        if (next2) { stage(bufi, 0, kt + 2); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else       { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(1, 0);
-        if (next2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // tile kt+1 landed; kt+2's first half in flight
-        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         barrier();
     };
 
@@ -172,10 +185,12 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     else        { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     barrier();
 
+    if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; kt += 2) {
         tile(kt, 0);
         tile(kt + 1, 1);
     }
+    if (wr == 0) barrier();               // every wave executes the same number of barriers
 
     // ---- epilogue: lane owns C[m][n..n+3] ----
     const int m_base = m0 + wr * 128 + frow;

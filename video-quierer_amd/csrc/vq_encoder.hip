@@ -190,8 +190,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     }
     {   // E8-E10
         Prof p(e, C_POOL);
-        hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(n), dim3(256), 0, st, e->x, e->post_g, e->post_b,
-                           e->w_proj, d_out_f32, d_out_f16, T, c.proj_dim, c.ln_eps);
+        hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(cdiv(n, POOL_IMGS)), dim3(256), 0, st, e->x, e->post_g, e->post_b,
+                           e->w_proj, d_out_f32, d_out_f16, n, T, c.proj_dim, c.ln_eps);
     }
     VQ_HIP(hipGetLastError());
     e->last_n = n;
