@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=BATCH, help="frames per step per GPU (BASELINE config: 256)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight per GPU: consecutive steps alternate between this many encoder "
+                         "handles on separate HIP streams, so one batch's tail workgroups overlap the next batch")
     return ap.parse_args()
 
 
@@ -55,7 +59,9 @@ def gemm_flops(cls, rows, cfg):
 
 
 def main():
+    global BATCH
     args = parse()
+    BATCH = args.batch
     import torch
     import torch.distributed as dist
 
@@ -77,21 +83,31 @@ def main():
     _lib.init(local)
     cfg = VIT_B_32
     weights = seeded_weights(cfg, 1234)
-    enc = VitEncoder(cfg, weights, max_batch=BATCH, device=local)
-    stream = torch.cuda.current_stream(dev)
-    enc.set_stream(stream.cuda_stream)      # same stream as torch/RCCL: no host sync between encode and all-gather
+    # one encoder handle per in-flight batch, each on its own torch-owned HIP stream (torch owns it so the
+    # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local) for _ in range(nstreams)]
+    for e_, s_ in zip(encs, streams):
+        e_.set_stream(s_.cuda_stream)
+    enc, stream = encs[0], streams[0]
 
     # synthetic frames, device resident (the reference's randint(0,255) convention), 4 distinct batches per rank
     gen = torch.Generator(device=dev)
     gen.manual_seed(20250824 + rank)
     pool = [torch.randint(0, 255, (BATCH, 224, 224, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(4)]
-    emb = torch.empty((BATCH, cfg.proj_dim), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) if world > 1 else None
+    embs = [torch.empty((BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) for _ in range(nstreams)]
+    gath = [torch.empty((world * BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) if world > 1 else None
+            for _ in range(nstreams)]
+    emb = embs[0]
+    torch.cuda.synchronize(dev)
 
     def step(i):
-        enc.encode_device(pool[i % len(pool)].data_ptr(), BATCH, emb.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, emb)
+        j = i % nstreams
+        with torch.cuda.stream(streams[j]):
+            encs[j].encode_device(pool[i % len(pool)].data_ptr(), BATCH, embs[j].data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(gath[j], embs[j])
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -119,7 +135,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: batch-256 ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
                                "device-resident input (H2D excluded), seeded random-init weights",
-                   "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world,
+                   "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,
                    "parallelism": f"dp{world} (frame shards; RCCL all-gather of embeddings per step)" if world > 1 else "single GPU"},
         "encode_mfma_frac_whole_pass": frames_per_s / world * FLOP_PER_FRAME / PEAK_BF16,
     }
@@ -229,7 +245,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    enc.close()
+    for e_ in encs:
+        e_.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -106,6 +106,11 @@ int vq_encoder_debug_read(vq_encoder* enc, const char* name, int rows, float* ou
  * two-phase, 2 = 256x256 phased). */
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C);
 
+/* Diagnostic build of the 256x256 mainloop with in-kernel s_memtime stamps: workgroup 0, 8 waves x
+ * 768 stamps (3 per phase: start of read half, after the first barrier, after the MFMAs).
+ * diag: bit0 skip the in-loop DMA, bit1 skip the ds_reads, bit2 skip the MFMAs (timing ablations; results invalid). */
+int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stamps);
+
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;
 

@@ -338,62 +338,77 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 // ============================ pooling head ===================================
 // CLS token -> post_layernorm -> visual_projection (fp32 weights, no bias) ->
 // L2 normalise (x / max(||x||, 1e-12), F.normalize)                 (E8-E10)
-// One 256-thread workgroup per POOL_IMGS images: every projection row is read once
-// per workgroup and dotted against all its images (lane-split over `hidden`, wave
-// reduction), so the 1.5 MB weight is re-read B/POOL_IMGS times instead of B times.
-constexpr int POOL_IMGS = 4;
+// One 256-thread workgroup per POOL_IMGS images.  Each wave LayerNorms two CLS rows
+// into LDS; then thread t owns outputs t and t+256 for all POOL_IMGS images and walks
+// k: the projection is stored TRANSPOSED [hidden][proj_dim] so the weight reads are
+// coalesced across threads and shared by the images; the normalised rows are LDS
+// broadcasts.  proj_dim <= 512.
+constexpr int POOL_IMGS = 8;
 template <int NV>
 __global__ __launch_bounds__(256)
 void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                         const float* __restrict__ b, const float* __restrict__ wproj,
+                         const float* __restrict__ b, const float* __restrict__ wproj_t,
                          float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
                          int n_images, int tokens, int proj_dim, float eps) {
     constexpr int H = NV * 256;
-    __shared__ float feat[POOL_IMGS][2048];
+    __shared__ __attribute__((aligned(16))) float xn[POOL_IMGS][H];
     __shared__ float red[POOL_IMGS][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img0 = blockIdx.x * POOL_IMGS;
-    float4 v[POOL_IMGS][NV];
 #pragma unroll
-    for (int im = 0; im < POOL_IMGS; ++im) {
-        const int img = min(img0 + im, n_images - 1);          // tail workgroup: duplicate the last image
+    for (int j = 0; j < POOL_IMGS / 4; ++j) {
+        const int im = wave * (POOL_IMGS / 4) + j;
+        const int img = min(img0 + im, n_images - 1);            // tail workgroup: duplicate the last image
+        float4 v[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[im][i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
-        ln_row<NV>(v[im], g, b, lane, eps, H);                   // every wave normalises the same rows
+        for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
+        ln_row<NV>(v, g, b, lane, eps, H);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *(float4*)(&xn[im][(i * 64 + lane) * 4]) = v[i];
     }
-    float ss[POOL_IMGS];
+    __syncthreads();
+    float acc[2][POOL_IMGS];
 #pragma unroll
-    for (int im = 0; im < POOL_IMGS; ++im) ss[im] = 0.f;
-    for (int o = wave; o < proj_dim; o += 4) {
-        const float* wr = wproj + (size_t)o * H;
-        float4 w[NV];
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) w[i] = *(const float4*)(wr + (i * 64 + lane) * 4);
+        for (int im = 0; im < POOL_IMGS; ++im) acc[o][im] = 0.f;
+    const int o0 = tid, o1 = tid + 256;
+    const bool has0 = o0 < proj_dim, has1 = o1 < proj_dim;
+    for (int k = 0; k < H; k += 4) {
+        float w0[4], w1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            w0[kk] = has0 ? wproj_t[(size_t)(k + kk) * proj_dim + o0] : 0.f;
+            w1[kk] = has1 ? wproj_t[(size_t)(k + kk) * proj_dim + o1] : 0.f;
+        }
 #pragma unroll
         for (int im = 0; im < POOL_IMGS; ++im) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                acc += (v[im][i].x * w[i].x + v[im][i].y * w[i].y) + (v[im][i].z * w[i].z + v[im][i].w * w[i].w);
-            acc = wave_sum(acc);
-            if (lane == 0) feat[im][o] = acc;
-            ss[im] += acc * acc;                                 // identical in every lane
+            const float4 xv = *(const float4*)(&xn[im][k]);      // same address in every lane: broadcast
+            acc[0][im] += xv.x * w0[0]; acc[0][im] += xv.y * w0[1]; acc[0][im] += xv.z * w0[2]; acc[0][im] += xv.w * w0[3];
+            acc[1][im] += xv.x * w1[0]; acc[1][im] += xv.y * w1[1]; acc[1][im] += xv.z * w1[2]; acc[1][im] += xv.w * w1[3];
         }
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int im = 0; im < POOL_IMGS; ++im) red[im][wave] = ss[im];
+    for (int im = 0; im < POOL_IMGS; ++im) {
+        const float s = wave_sum(acc[0][im] * acc[0][im] + acc[1][im] * acc[1][im]);
+        if (lane == 0) red[im][wave] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int im = 0; im < POOL_IMGS; ++im) {
         const int img = img0 + im;
-        if (img >= n_images) break;
-        const float nrm = fmaxf(sqrtf((red[im][0] + red[im][1]) + (red[im][2] + red[im][3])), 1e-12f);
-        for (int o = threadIdx.x; o < proj_dim; o += 256) {
-            const float e = feat[im][o] / nrm;
-            out_f32[(size_t)img * proj_dim + o] = e;
-            if (out_f16) out_f16[(size_t)img * proj_dim + o] = __builtin_bit_cast(uint16_t, (_Float16)e);
+        if (img < n_images) {
+            const float nrm = fmaxf(sqrtf((red[im][0] + red[im][1]) + (red[im][2] + red[im][3])), 1e-12f);
+            if (has0) {
+                const float e = acc[0][im] / nrm;
+                out_f32[(size_t)img * proj_dim + o0] = e;
+                if (out_f16) out_f16[(size_t)img * proj_dim + o0] = __builtin_bit_cast(uint16_t, (_Float16)e);
+            }
+            if (has1) {
+                const float e = acc[1][im] / nrm;
+                out_f32[(size_t)img * proj_dim + o1] = e;
+                if (out_f16) out_f16[(size_t)img * proj_dim + o1] = __builtin_bit_cast(uint16_t, (_Float16)e);
+            }
         }
     }
 }

@@ -37,11 +37,15 @@ constexpr int G2_HALF = 128 * G2_BK * 2;          // 16 KiB: 128 rows x 64 k
 constexpr int G2_BUF = 4 * G2_HALF;               // 64 KiB per K-tile buffer
 constexpr int G2_LDS_BYTES = 2 * G2_BUF;          // 128 KiB
 
-template <bool IS_F16, class Epi>
+// STAMP = diagnostic build only (vq_debug_gemm_stamps): lane 0 of every wave of workgroup 0 records
+// s_memtime at the three points of each phase into `stamps` (never used by the product path).
+constexpr int G2_MAX_STAMPS = 768;
+template <bool IS_F16, class Epi, bool STAMP = false>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                        const uint16_t* __restrict__ W, int ldw,
-                       int K, int tiles_n, Epi epi) {
+                       int K, int tiles_n, Epi epi, unsigned long long* __restrict__ stamps = nullptr,
+                       int diag = 0 /* STAMP builds: bit0 skip DMA in the loop, bit1 skip ds_reads, bit2 skip MFMAs */) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,7 +74,9 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     const int piece_off = wave * 2048;                         // pieces 2w,2w+1 are contiguous
 
     // which: 0 = A half 0, 1 = A half 1, 2 = W half 0, 3 = W half 1
+    bool in_loop = false;
     auto stage = [&](int buf, int which, int kt) {
+        if constexpr (STAMP) { if (in_loop && (diag & 1)) return; }
         char* dst = smem + buf * G2_BUF + which * G2_HALF + piece_off;
         const int koff = kt * G2_BK;
         if (which < 2) {
@@ -97,10 +103,17 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     frag af[4][2], wf[2][2];
+    if constexpr (STAMP) {                 // diag builds may skip the loads: keep the registers defined
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { af[i][0] = frag{}; af[i][1] = frag{}; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { wf[j][0] = frag{}; wf[j][1] = frag{}; }
+    }
 
     const int nk = K / G2_BK;
 
     auto load_a = [&](const char* buf, int hm) {
+        if constexpr (STAMP) { if (diag & 2) return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -108,6 +121,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                 af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
     };
     auto load_w = [&](const char* buf, int hn) {
+        if constexpr (STAMP) { if (diag & 2) return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -115,6 +129,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                 wf[j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
     };
     auto mfma_quadrant = [&](int hm, int hn) {
+        if constexpr (STAMP) { if (diag & 4) return; }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -129,6 +144,16 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if constexpr (STAMP) {
+            if (blockIdx.x == 0 && stamp_i < G2_MAX_STAMPS) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) stamps[wave * G2_MAX_STAMPS + stamp_i] = t;
+                ++stamp_i;
+            }
+        }
     };
 
     // One K-tile = 4 phases; a phase = read half {ds_reads, one half-tile of DMA} | barrier |
@@ -148,34 +173,46 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
         // phase 1: quadrant (0,0)
+        stamp();
         load_a(buf, 0); load_w(buf, 0);
         if (next) stage(bufi ^ 1, 1, kt + 1);
         barrier();
+        stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(0, 0);
+        stamp();
         barrier();
         // phase 2: quadrant (0,1)
+        stamp();
         load_w(buf, 1);
         if (next) stage(bufi ^ 1, 2, kt + 1);
         barrier();
+        stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(0, 1);
+        stamp();
         barrier();
         // phase 3: quadrant (1,1)
+        stamp();
         load_a(buf, 1);
         if (next) stage(bufi ^ 1, 3, kt + 1);
         barrier();
+        stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(1, 1);
+        stamp();
         barrier();
         // phase 4: quadrant (1,0); this buffer's A half 0 is dead -> start tile kt+2's A half 0,
         // then retire everything older (tile kt+1 complete) with one half-tile left in flight
+        stamp();
         load_w(buf, 0);
         if (next2) { stage(bufi, 0, kt + 2); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         else       { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         barrier();
+        stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(1, 0);
+        stamp();
         barrier();
     };
 
@@ -185,6 +222,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     else        { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     barrier();
 
+    in_loop = true;
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; kt += 2) {
         tile(kt, 0);
@@ -202,6 +240,152 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
             epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ring variant: same 256x256 tile / wave layout, but the K loop advances in 32-wide sub-tiles
+// through a 4-slot LDS ring (4 x {A 256 rows x 64 B, W 256 rows x 64 B} = 128 KiB).
+//   phase p (one per sub-tile): read half  = 12 ds_read_b128 (8 A + 4 W fragments of slot p%4),
+//                                            4 LDS-DMA pieces refilling slot (p-1)%4 with sub-tile p+3,
+//                                            s_waitcnt vmcnt(8) (sub-tile p+1 landed; 8 pieces stay in
+//                                            flight), s_waitcnt lgkmcnt(0), s_barrier
+//                              MFMA half  = 32 MFMAs (the wave's whole 128x64 tile x K=32), s_barrier
+// Twice the MFMAs per barrier pair of the 4-phase-per-K-tile kernel above (measured there with
+// s_memtime stamps: ~200 cycles of barrier/restart per half phase against 256 cycles of MFMA), a
+// prefetch distance of three sub-tiles, and every DMA wait counted.  The two wave groups run
+// staggered by one barrier.  Hazards (b(k) = k-th barrier; group 0 phase p: pre b(2p), close b(2p+1);
+// group 1: pre b(2p+1), close b(2p+2)):
+//   WAR  slot (p-1)%4 was last read in phase p-1; both groups retire those reads (lgkmcnt(0)) BEFORE
+//        their pre-MFMA barrier, i.e. before b(2p-2) / b(2p-1); the earliest refill is issued after b(2p-1).
+//   RAW  sub-tile p+1 is retired by every issuer's vmcnt in the read half of phase p (before b(2p) /
+//        b(2p+1)); it is first read after b(2p+1) (group 0) / b(2p+2) (group 1).
+// 64-byte LDS rows: chunk c of row r is stored at chunk c ^ (2*((r>>3)&1)) — conflict-free for the four
+// ds_read_b128 lane groups (brute-forced against the bank model of MI355X_MICROARCH.md §LDS).
+constexpr int G3_SUB_K = 32;
+constexpr int G3_PART = 256 * G3_SUB_K * 2;       // 16 KiB: 256 rows x 64 B (one operand of one sub-tile)
+constexpr int G3_SLOT = 2 * G3_PART;              // 32 KiB
+constexpr int G3_LDS_BYTES = 4 * G3_SLOT;         // 128 KiB
+
+template <bool IS_F16, class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
+                            const uint16_t* __restrict__ W, int ldw,
+                            int K, int tiles_n, Epi epi) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * G2_BM;
+    const int n0 = (wg % tiles_n) * G2_BN;
+
+    // LDS-DMA: a 1-KiB piece = 16 rows x 64 B; wave w fills pieces 2w, 2w+1 (rows 32w..32w+31) of A and of W
+    const int srow = lane >> 2;                                   // row inside the piece
+    const int schunk = (lane & 3) ^ (((lane >> 5) & 1) * 2);      // logical chunk stored at physical slot lane&3
+    const uint16_t* a_src[2];
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + srow;
+        a_src[i] = A + (size_t)(m0 + row) * lda + schunk * 8;
+        w_src[i] = W + (size_t)(n0 + row) * ldw + schunk * 8;
+    }
+    const int piece_off = wave * 2048;
+
+    auto stage = [&](int slot, int sub) {
+        char* dst = smem + slot * G3_SLOT + piece_off;
+        const int koff = sub * G3_SUB_K;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[0] + koff), (lds_void_t*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[1] + koff), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[0] + koff), (lds_void_t*)(dst + G3_PART), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[1] + koff), (lds_void_t*)(dst + G3_PART + 1024), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int pchunk = fgrp ^ (((frow >> 3) & 1) * 2);
+    const int a_base = (wr * 128 + frow) * 64 + pchunk * 16;                 // + mi*1024
+    const int w_base = G3_PART + (wc * 64 + frow) * 64 + pchunk * 16;        // + ni*1024
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsub = K / G3_SUB_K;
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    auto phase = [&](int p, int slot) {
+        const char* buf = smem + slot * G3_SLOT;
+        frag af[8], wf[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const frag*)(buf + a_base + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *(const frag*)(buf + w_base + j * 1024);
+        if (p + 3 < nsub) {
+            stage((slot + 3) & 3, p + 3);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = op::run(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+    };
+
+    // prologue: sub-tiles 0,1,2 in flight, 0 landed
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    barrier();
+
+    if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
+    for (int p = 0; p < nsub; p += 4) {
+        phase(p, 0); phase(p + 1, 1); phase(p + 2, 2); phase(p + 3, 3);
+    }
+    if (wr == 0) barrier();
+
+    const int m_base = m0 + wr * 128 + frow;
+    const int n_base = n0 + wc * 64 + fgrp * 4;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256_ring(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                                  int M, int N, int K, const Epi& epi) {
+    VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % 128 == 0,
+             "gemm_tn256_ring: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn256_ring: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                              int M, int N, int K, const Epi& epi) {
@@ -217,7 +401,19 @@ static int launch_gemm_tn256(hipStream_t st, const uint16_t* A, int lda, const u
     }
     const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
     hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
-                       A, lda, W, ldw, K, tiles_n, epi);
+                       A, lda, W, ldw, K, tiles_n, epi, (unsigned long long*)nullptr, 0);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256_stamped(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                                     int M, int N, int K, const Epi& epi, unsigned long long* d_stamps, int diag = 0) {
+    VQ_CHECK(M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0, "gemm_tn256_stamped: shape not tile-aligned");
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_kernel<IS_F16, Epi, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                       G2_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, d_stamps, diag);
     VQ_HIP(hipGetLastError());
     return 0;
 }
@@ -228,7 +424,8 @@ template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
-    const bool want256 = force == 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
+    const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
+    if (fits256 && want256 && force == 3) return launch_gemm_tn256_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (fits256 && want256 && force != 1) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }

@@ -103,4 +103,29 @@ int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags
     return rc;
 }
 
+// Diagnostic: the 256x256 kernel with in-kernel s_memtime stamps (workgroup 0, 8 waves x 768 stamps).
+int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stamps /*[8][768]*/) {
+    VQ_TRY(require_init());
+    VQ_CHECK(stamps, "vq_debug_gemm_stamps: null argument");
+    uint16_t *dA = nullptr, *dW = nullptr; float* dC = nullptr; unsigned long long* dS = nullptr;
+    VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2));
+    VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4)); VQ_HIP(hipMalloc(&dS, 8 * G2_MAX_STAMPS * 8));
+    std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t r = 12345;
+    for (auto& v : a16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    for (auto& v : w16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemset(dS, 0, 8 * G2_MAX_STAMPS * 8));
+    int rc = 0;
+    for (int rep = 0; rep < 3 && rc == 0; ++rep)
+        rc = launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, dS, diag);
+    if (rc == 0) {
+        hipError_t e = hipMemcpy(stamps, dS, 8 * G2_MAX_STAMPS * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(VQ_ERR_HIP, "stamps copy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dS);
+    return rc;
+}
+
 }  // extern "C"

@@ -227,7 +227,7 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
     VQ_CHECK(c.heads % 4 == 0, "vq_encoder_create: heads must be a multiple of 4");
     VQ_CHECK((c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0, "vq_encoder_create: hidden %d / mlp %d unsupported",
              c.hidden, c.mlp);
-    VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 2048, "vq_encoder_create: proj_dim %d out of range", c.proj_dim);
+    VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 512, "vq_encoder_create: proj_dim %d out of range (<= 512)", c.proj_dim);
     const int patch_k_raw = 3 * c.patch_size * c.patch_size;
     const int patch_k = (int)round_up(patch_k_raw, GEMM_BK);
     VQ_CHECK(patch_k == patch_k_raw, "vq_encoder_create: patch K %d must be a multiple of 64", patch_k_raw);
@@ -309,7 +309,13 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));
     e->post_b = A.take<float>(H);             UP(upload_f32(e->post_b, weights[wi++], H));
     e->w_proj = A.take<float>((size_t)c.proj_dim * H);
-    UP(upload_f32(e->w_proj, weights[wi++], (size_t)c.proj_dim * H));
+    {   // stored transposed [hidden][proj_dim]: coalesced reads in pool_project_kernel
+        const float* wp = weights[wi++];
+        std::vector<float> wt((size_t)c.proj_dim * H);
+        for (int o = 0; o < c.proj_dim; ++o)
+            for (size_t k = 0; k < H; ++k) wt[k * c.proj_dim + o] = wp[(size_t)o * H + k];
+        UP(upload_f32(e->w_proj, wt.data(), wt.size()));
+    }
 #undef UP
     // workspace
     e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
