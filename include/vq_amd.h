@@ -111,6 +111,11 @@ int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags
  * diag: bit0 skip the in-loop DMA, bit1 skip the ds_reads, bit2 skip the MFMAs (timing ablations; results invalid). */
 int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stamps);
 
+/* Diagnostic: average time of one GEMM mainloop with parts removed (results invalid).  kernel: 1 =
+ * 128x128, 2 = 256x256 four-phase, 3 = 256x256 ring; diag: bit0 no in-loop DMA, bit1 no ds_reads,
+ * bit2 no MFMAs, bit3 no barriers (ring only). */
+int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, float* ms_avg);
+
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vq_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_float)]),
     "vq_debug_gemm": (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_debug_gemm_stamps": (c_int, [c_int, c_int, c_int, c_int, POINTER(ctypes.c_uint64)]),
+    "vq_debug_gemm_ablate": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_index_create": (c_int, [c_int, POINTER(c_void_p)]),
     "vq_index_destroy": (c_int, [c_void_p]),
     "vq_index_add": (c_int, [c_void_p, POINTER(c_float), c_int64, c_int]),

@@ -55,6 +55,37 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Epilogue staging.  The MFMA result layout gives a lane 4 consecutive n for ONE m, so a wave-wide
+// store touches 16 different rows with 64-byte pieces; measured on the 256x256 kernel that store
+// pattern alone cost ~30-40 us per launch (39 MB of fp32 at <1 TB/s).  Instead every wave transposes
+// its accumulators through a private LDS strip (32 rows x 64 cols fp32, row stride 272 B: conflict-free
+// for the b128 write and read lane groups) and calls the epilogue functor with ROW-contiguous data:
+// 16 lanes x 16 B = one 256-byte row segment, 4 rows per wave instruction.
+constexpr int EPI_ROW_BYTES = 272;
+constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
+
+template <int MI, class Epi>      // wave tile = MI*16 rows x 64 cols; acc[mi][ni] = C[16mi + lane&15][16ni + 4(lane>>4) ..+3]
+__device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI][4], int m_wave0, int n_wave0,
+                                              int lane, const Epi& epi) {
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int rrow = lane >> 4, rcol = lane & 15;
+#pragma unroll
+    for (int pass = 0; pass < MI / 2; ++pass) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *(f32x4*)(strip + (h * 16 + frow) * EPI_ROW_BYTES + (ni * 16 + fgrp * 4) * 4) = acc[pass * 2 + h][ni];
+        // same wave, in-order LDS: the reads below see the writes above
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + rrow;
+            const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
+            epi(m_wave0 + pass * 32 + row, n_wave0 + rcol * 4, v);
+        }
+    }
+}
+
 template <bool IS_F16, class Epi>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
@@ -141,14 +172,8 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
         __syncthreads();      // next buffer landed (vmcnt(0)) and this one is free to refill
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3] ----
-    const int m_base = m0 + wm * 64 + frow;
-    const int n_base = n0 + wn * 64 + fgrp * 4;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+    // ---- epilogue (the last __syncthreads() retired every fragment read: LDS is free) ----
+    wave_epilogue<4>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wm * 64, n0 + wn * 64, lane, epi);
 }
 
 template <bool IS_F16, class Epi>

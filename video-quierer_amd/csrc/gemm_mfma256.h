@@ -40,7 +40,7 @@ constexpr int G2_LDS_BYTES = 2 * G2_BUF;          // 128 KiB
 // STAMP = diagnostic build only (vq_debug_gemm_stamps): lane 0 of every wave of workgroup 0 records
 // s_memtime at the three points of each phase into `stamps` (never used by the product path).
 constexpr int G2_MAX_STAMPS = 768;
-template <bool IS_F16, class Epi, bool STAMP = false>
+template <bool IS_F16, class Epi, bool STAMP = false, bool DIAG = false>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                        const uint16_t* __restrict__ W, int ldw,
@@ -76,7 +76,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     // which: 0 = A half 0, 1 = A half 1, 2 = W half 0, 3 = W half 1
     bool in_loop = false;
     auto stage = [&](int buf, int which, int kt) {
-        if constexpr (STAMP) { if (in_loop && (diag & 1)) return; }
+        if constexpr (DIAG) { if (in_loop && (diag & 1)) return; }
         char* dst = smem + buf * G2_BUF + which * G2_HALF + piece_off;
         const int koff = kt * G2_BK;
         if (which < 2) {
@@ -103,7 +103,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     frag af[4][2], wf[2][2];
-    if constexpr (STAMP) {                 // diag builds may skip the loads: keep the registers defined
+    if constexpr (DIAG) {                  // diag builds may skip the loads: keep the registers defined
 #pragma unroll
         for (int i = 0; i < 4; ++i) { af[i][0] = frag{}; af[i][1] = frag{}; }
 #pragma unroll
@@ -113,7 +113,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     const int nk = K / G2_BK;
 
     auto load_a = [&](const char* buf, int hm) {
-        if constexpr (STAMP) { if (diag & 2) return; }
+        if constexpr (DIAG) { if (diag & 2) return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -121,7 +121,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                 af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
     };
     auto load_w = [&](const char* buf, int hn) {
-        if constexpr (STAMP) { if (diag & 2) return; }
+        if constexpr (DIAG) { if (diag & 2) return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -129,7 +129,7 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                 wf[j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
     };
     auto mfma_quadrant = [&](int hm, int hn) {
-        if constexpr (STAMP) { if (diag & 4) return; }
+        if constexpr (DIAG) { if (diag & 4) return; }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -229,15 +229,10 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
         tile(kt + 1, 1);
     }
     if (wr == 0) barrier();               // every wave executes the same number of barriers
+    barrier();                            // both groups past their last fragment reads before LDS is reused
 
-    // ---- epilogue: lane owns C[m][n..n+3] ----
-    const int m_base = m0 + wr * 128 + frow;
-    const int n_base = n0 + wc * 64 + fgrp * 4;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+    // ---- epilogue: every wave is past its last fragment read (final barrier) -> LDS strips are free ----
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,11 +259,11 @@ constexpr int G3_PART = 256 * G3_SUB_K * 2;       // 16 KiB: 256 rows x 64 B (on
 constexpr int G3_SLOT = 2 * G3_PART;              // 32 KiB
 constexpr int G3_LDS_BYTES = 4 * G3_SLOT;         // 128 KiB
 
-template <bool IS_F16, class Epi>
+template <bool IS_F16, class Epi, bool DIAG = false>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
                             const uint16_t* __restrict__ W, int ldw,
-                            int K, int tiles_n, Epi epi) {
+                            int K, int tiles_n, Epi epi, int diag = 0) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,26 +320,35 @@ void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
     auto phase = [&](int p, int slot) {
         const char* buf = smem + slot * G3_SLOT;
         frag af[8], wf[4];
+        if (DIAG && (diag & 2)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const frag*)(buf + a_base + i * 1024);
+            for (int i = 0; i < 8; ++i) af[i] = frag{};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *(const frag*)(buf + w_base + j * 1024);
+            for (int j = 0; j < 4; ++j) wf[j] = frag{};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(const frag*)(buf + a_base + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *(const frag*)(buf + w_base + j * 1024);
+        }
         if (p + 3 < nsub) {
-            stage((slot + 3) & 3, p + 3);
+            if (!(DIAG && (diag & 1))) stage((slot + 3) & 3, p + 3);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        barrier();
-        __builtin_amdgcn_s_setprio(1);
+        if (!(DIAG && (diag & 8))) barrier();
+        if (!(DIAG && (diag & 4))) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = op::run(wf[j], af[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        barrier();
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = op::run(wf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (!(DIAG && (diag & 8))) barrier();
     };
 
     // prologue: sub-tiles 0,1,2 in flight, 0 landed
@@ -358,13 +362,8 @@ void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
     }
     if (wr == 0) barrier();
 
-    const int m_base = m0 + wr * 128 + frow;
-    const int n_base = n0 + wc * 64 + fgrp * 4;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            epi(m_base + mi * 16, n_base + ni * 16, acc[mi][ni]);
+    barrier();                            // group 1's last fragment reads are retired before anyone reuses LDS
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
 }
 
 template <bool IS_F16, class Epi>
@@ -381,7 +380,19 @@ static int launch_gemm_tn256_ring(hipStream_t st, const uint16_t* A, int lda, co
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
-                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi);
+                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, 0);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256_ring_diag(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                                       int M, int N, int K, const Epi& epi, int diag) {
+    VQ_CHECK(M % G2_BM == 0 && N % G2_BN == 0 && K % 128 == 0, "gemm_tn256_ring_diag: shape not tile-aligned");
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+    hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, diag);
     VQ_HIP(hipGetLastError());
     return 0;
 }
@@ -410,10 +421,17 @@ template <bool IS_F16, class Epi>
 static int launch_gemm_tn256_stamped(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                                      int M, int N, int K, const Epi& epi, unsigned long long* d_stamps, int diag = 0) {
     VQ_CHECK(M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0, "gemm_tn256_stamped: shape not tile-aligned");
-    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_kernel<IS_F16, Epi, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
-    hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
-                       G2_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, d_stamps, diag);
+    if (d_stamps) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_kernel<IS_F16, Epi, true, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+        hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi, true, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                           G2_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, d_stamps, diag);
+    } else {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_kernel<IS_F16, Epi, false, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+        hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi, false, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                           G2_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, (unsigned long long*)nullptr, diag);
+    }
     VQ_HIP(hipGetLastError());
     return 0;
 }

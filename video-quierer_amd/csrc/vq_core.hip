@@ -128,4 +128,38 @@ int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stam
     return rc;
 }
 
+// Diagnostic: time one mainloop with parts removed (results invalid).  kernel 2 = 4-phase, 3 = ring.
+// diag: bit0 no in-loop DMA, bit1 no ds_reads, bit2 no MFMAs, bit3 (ring only) no barriers.
+int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, float* ms_avg) {
+    VQ_TRY(require_init());
+    VQ_CHECK(ms_avg && reps > 0, "vq_debug_gemm_ablate: bad argument");
+    uint16_t *dA = nullptr, *dW = nullptr; float* dC = nullptr;
+    VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2)); VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4));
+    std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t r = 777;
+    for (auto& v : a16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    for (auto& v : w16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    VQ_HIP(hipEventCreate(&e0)); VQ_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    auto once = [&]() {
+        if (kernel == 3) return launch_gemm_tn256_ring_diag<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, diag);
+        if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        return launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, nullptr, diag);
+    };
+    for (int i = 0; i < 3 && rc == 0; ++i) rc = once();
+    VQ_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps && rc == 0; ++i) rc = once();
+    VQ_HIP(hipEventRecord(e1, nullptr));
+    VQ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
+    return rc;
+}
+
 }  // extern "C"
