@@ -29,6 +29,7 @@
 #pragma once
 #include "vq_common.h"
 #include "gemm_mfma.h"
+#include "gemm_mfma256.h"
 #include "knn_kernels.h"
 
 namespace vq {
@@ -162,6 +163,201 @@ void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second-generation scan: the 256x256 four-phase mainloop of gemm_mfma256.h (staggered wave groups,
+// counted vmcnt, raw barriers) with the top-2 fold as its "epilogue".  A workgroup covers 256 queries
+// x 2048 matrix rows (8 row tiles, one continuous K loop of 8*dim/64 K-tiles); wave (wr, wc) owns
+// queries 128 wr .. +127 and rows 64 wc .. +63 of every tile; stream = (2048-row range, wc, lane
+// group g) = rows range*2048 + t*256 + wc*64 + ni*16 + 4g + r, local index t*16 + ni*4 + r.
+// The fold of a finished quadrant (32 accumulators) runs in the read half of the following phase,
+// i.e. under the partner group's MFMAs.
+constexpr int SCAN2_QT = 256;
+constexpr int SCAN2_RANGE = 2048;
+
+__host__ __device__ inline int64_t scan2_row_of(int64_t stream, int local) {
+    const int64_t range = stream >> 4;
+    const int wc = (int)(stream >> 2) & 3, g = (int)stream & 3;
+    const int t = local >> 4, ni = (local >> 2) & 3, r = local & 3;
+    return range * SCAN2_RANGE + t * 256 + wc * 64 + ni * 16 + 4 * g + r;
+}
+
+__global__ __launch_bounds__(G2_THREADS, 2)
+void scan2_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
+                           int dim, int64_t n_valid, int q_tiles, int64_t q_pad,
+                           uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+    typedef mfma_op<true> op;
+    typedef op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int range = wg / q_tiles;                      // query tile fastest: neighbours share the matrix rows in L2
+    const int m0 = (wg - range * q_tiles) * SCAN2_QT;
+    const int64_t n0 = (int64_t)range * SCAN2_RANGE;
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    const uint16_t* a_src[2];
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + srow;
+        const int chunk = sslot ^ ((row >> 1) & 7);
+        a_src[i] = Q16 + (size_t)(m0 + row) * dim + chunk * 8;
+        w_src[i] = X16 + (size_t)(n0 + row) * dim + chunk * 8;
+    }
+    const size_t half_rows = (size_t)128 * dim;
+    const int piece_off = wave * 2048;
+    const int nk = dim / G2_BK;                          // K-tiles per row tile
+    const int total = 8 * nk;                            // flattened K-tiles
+
+    // which: 0/1 = query halves, 2/3 = matrix-row halves; kt = flattened K-tile index
+    auto stage = [&](int buf, int which, int kt) __attribute__((always_inline)) {
+        char* dst = smem + buf * G2_BUF + which * G2_HALF + piece_off;
+        const int t = kt / nk, kk = kt - t * nk;
+        if (which < 2) {
+            const size_t off = (which ? half_rows : 0) + (size_t)kk * G2_BK;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[0] + off), (lds_void_t*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[1] + off), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        } else {
+            const size_t off = (size_t)t * 256 * dim + ((which & 1) ? half_rows : 0) + (size_t)kk * G2_BK;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[0] + off), (lds_void_t*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[1] + off), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        }
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag af[4][2], wf[2][2];
+    const float NEG = -__builtin_inff();
+    float m1[8], m2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { m1[i] = NEG; m2[i] = NEG; }
+
+    auto load_a = [&](const char* buf, int hm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf, int hn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
+    };
+    auto mfma_quadrant = [&](int hm, int hn) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // fold quadrant (hm, hn) of row tile t into the running top-2 and clear it
+    auto fold = [&](int hm, int hn, int t) __attribute__((always_inline)) {
+        const bool ragged = n0 + (int64_t)(t + 1) * 256 > n_valid;     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mi = hm * 4 + i, ni = hn * 2 + j;
+                    float v = acc[mi][ni][r];
+                    if (ragged && n0 + t * 256 + wc * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = NEG;
+                    const uint32_t kb = (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)(t * 16 + ni * 4 + r);
+                    const float kf = __builtin_bit_cast(float, kb);
+                    m2[mi] = __builtin_amdgcn_fmed3f(m1[mi], m2[mi], kf);
+                    m1[mi] = fmaxf(m1[mi], kf);
+                    acc[mi][ni][r] = 0.f;
+                }
+    };
+    auto barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // One K-tile (same four phases, hazards and waits as gemm_tn256_kernel).  `last` = final K-tile of
+    // a row tile: each quadrant is folded in the read half of the phase after its last MFMAs; the
+    // fourth quadrant's fold lands in phase 1 of the next K-tile (`fold_prev`).
+    auto tile = [&](int kt, int bufi, bool last, bool fold_prev, int t) __attribute__((always_inline)) {
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < total, next2 = kt + 2 < total;
+        if (fold_prev) fold(1, 0, t - 1);
+        load_a(buf, 0); load_w(buf, 0);
+        if (next) stage(bufi ^ 1, 1, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 0);
+        barrier();
+        if (last) fold(0, 0, t);
+        load_w(buf, 1);
+        if (next) stage(bufi ^ 1, 2, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 1);
+        barrier();
+        if (last) fold(0, 1, t);
+        load_a(buf, 1);
+        if (next) stage(bufi ^ 1, 3, kt + 1);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 1);
+        barrier();
+        if (last) fold(1, 1, t);
+        load_w(buf, 0);
+        if (next2) { stage(bufi, 0, kt + 2); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else       { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 0);
+        barrier();
+    };
+
+    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
+    if (total > 1) { stage(1, 0, 1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else           { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    barrier();
+
+    if (wr == 1) barrier();
+    int kk = 0, t = 0;
+    for (int kt = 0; kt < total; kt += 2) {              // nk is even: a row tile never ends on an odd kt
+        tile(kt, 0, false, kk == 0 && t > 0, t);
+        ++kk;
+        tile(kt + 1, 1, kk + 1 == nk, false, t);
+        if (++kk == nk) { kk = 0; ++t; }
+    }
+    fold(1, 0, 7);
+    if (wr == 0) barrier();
+
+    const int64_t stream = (int64_t)range * 16 + wc * 4 + fgrp;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int q = m0 + wr * 128 + mi * 16 + frow;
+        *(uint2*)(keys + ((size_t)stream * q_pad + q) * 2) =
+            uint2{__builtin_bit_cast(uint32_t, m1[mi]), __builtin_bit_cast(uint32_t, m2[mi])};
+    }
+}
+
 // queries fp32 [nq][dim] -> fp16 [q_pad][dim], pad rows zero
 __global__ __launch_bounds__(256)
 void queries_to_f16_kernel(const float* __restrict__ q, uint16_t* __restrict__ q16, int nq, int64_t q_pad, int dim) {
@@ -203,7 +399,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                            const float* __restrict__ rows, int64_t n_valid, int dim,
                            const float* __restrict__ queries, int nq, int k,
                            int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
-                           int32_t* __restrict__ flags) {
+                           int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2 streams*/) {
     __shared__ float kept_v[RV_QPW][RV_SHARES * RV_KEEP];      // kept key values (with packed index bits)
     __shared__ int kept_s[RV_QPW][RV_SHARES * RV_KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
     __shared__ float share_floor[RV_QPW][RV_SHARES];           // upper bound of what a share dropped
@@ -276,7 +472,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         int row = -1; float d = __builtin_inff();
         if (src >= 0 && q_live && cand_key[ql][c] > NEG) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[ql][c]);
-            const int64_t r = scan_row_of(src >> 1, (int)(kb & 127u));
+            const int64_t r = layout == 2 ? scan2_row_of(src >> 1, (int)(kb & 127u)) : scan_row_of(src >> 1, (int)(kb & 127u));
             if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
         }
         cand_row[ql][c] = row; cand_dist[ql][c] = d;
@@ -333,7 +529,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         const float* qv2 = queries + (size_t)(q0 + qq) * dim;
         for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
             const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
-            const int64_t r = scan_row_of(resc_stream[qq][which], local);
+            const int64_t r = layout == 2 ? scan2_row_of(resc_stream[qq][which], local) : scan_row_of(resc_stream[qq][which], local);
             int row = -1; float d = __builtin_inff();
             if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv2, dim); }
             cand_row[qq][RV_C + i] = row; cand_dist[qq][RV_C + i] = d;

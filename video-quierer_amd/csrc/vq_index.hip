@@ -7,6 +7,7 @@
 #include "knn_scan_f16.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct vq_index {
     int32_t* d_fb_ids = nullptr; int64_t fbi_cap = 0;
     float* d_fb_dist = nullptr; int64_t fbd_cap = 0;
     int64_t stats[3] = {0, 0, 0};
+    int scan_version = 2;          // $VQ_AMD_SCAN: 2 = 256x256 phased mainloop (needs dim % 128 == 0), 1 = 128x128
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
@@ -64,7 +66,7 @@ struct Prof {
 int reserve_rows(vq_index* x, int64_t need) {
     if (need <= x->cap) return 0;
     int64_t ncap = std::max<int64_t>(need, std::max<int64_t>(1024, x->cap * 2));
-    ncap = round_up(ncap, SCAN_RANGE);        // the fp16 scan walks whole 1024-row ranges
+    ncap = round_up(ncap, SCAN2_RANGE);       // the fp16 scans walk whole 1024/2048-row ranges
     float* nr = nullptr; uint16_t* nh = nullptr;
     hipError_t e = hipMalloc((void**)&nr, (size_t)ncap * x->dim * 4);
     if (e != hipSuccess) return fail(VQ_ERR_OOM, "index: hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
@@ -142,25 +144,36 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
 // fp16 MFMA scan + exact re-score with proof; unproven queries go through search_exact.
 int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
     const int64_t n = x->size;
-    const int64_t n_pad = round_up(n, SCAN_RANGE);
+    const int ver = x->scan_version;                                   // 2: 256x256 phased mainloop, 1: 128x128
+    const int QT = ver == 2 ? SCAN2_QT : SCAN_QT;
+    const int RANGE = ver == 2 ? SCAN2_RANGE : SCAN_RANGE;
+    const int64_t n_pad = round_up(n, RANGE);
     const int64_t streams = n_pad / SCAN_STREAM_ROWS;
     const int64_t key_budget = (int64_t)1 << 27;                       // 128 Mi (stream,query) pairs = 1 GiB of keys
-    int64_t q_chunk = std::max<int64_t>(SCAN_QT, key_budget / streams / SCAN_QT * SCAN_QT);
-    q_chunk = std::min<int64_t>(q_chunk, round_up(nq, SCAN_QT));
+    int64_t q_chunk = std::max<int64_t>(QT, key_budget / streams / QT * QT);
+    q_chunk = std::min<int64_t>(q_chunk, round_up(nq, QT));
     VQ_TRY(reserve_buf(x->d_q16, x->q16_cap, q_chunk * x->dim));
     VQ_TRY(reserve_buf(x->d_keys, x->keys_cap, streams * q_chunk * 2));
-    VQ_TRY(reserve_buf(x->d_flags, x->flags_cap, round_up(nq, SCAN_QT)));
+    VQ_TRY(reserve_buf(x->d_flags, x->flags_cap, round_up(nq, QT)));
     if (x->hflags_cap < nq) {
         if (x->h_flags) (void)hipHostFree(x->h_flags);
         x->h_flags = nullptr; x->hflags_cap = 0;
         VQ_HIP(hipHostMalloc((void**)&x->h_flags, (size_t)round_up(nq, 1024) * 4));
         x->hflags_cap = round_up(nq, 1024);
     }
-    const int ranges = (int)(n_pad / SCAN_RANGE);
+    const int ranges = (int)(n_pad / RANGE);
+    if (ver == 2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            VQ_HIP(hipFuncSetAttribute((const void*)scan2_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G2_LDS_BYTES));
+            attr_set = true;
+        }
+    }
     for (int64_t q0 = 0; q0 < nq; q0 += q_chunk) {
         const int cur = (int)std::min<int64_t>(q_chunk, nq - q0);
-        const int64_t q_pad = round_up(cur, SCAN_QT);
-        const int q_tiles = (int)(q_pad / SCAN_QT);
+        const int64_t q_pad = round_up(cur, QT);
+        const int q_tiles = (int)(q_pad / QT);
         {
             Prof p(x, I_TO_F16);
             const int64_t total4 = q_pad * x->dim / 4;
@@ -169,14 +182,18 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
         {
             Prof p(x, I_MFMA_SCAN);
-            hipLaunchKernelGGL(scan_f16_top2_kernel, dim3(q_tiles * ranges), dim3(GEMM_THREADS), 0, x->stream, x->d_q16,
-                               x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
+            if (ver == 2)
+                hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(q_tiles * ranges), dim3(G2_THREADS), G2_LDS_BYTES, x->stream,
+                                   x->d_q16, x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
+            else
+                hipLaunchKernelGGL(scan_f16_top2_kernel, dim3(q_tiles * ranges), dim3(GEMM_THREADS), 0, x->stream, x->d_q16,
+                                   x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
         }
         {
             Prof p(x, I_RESCORE);
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                               d_dist_out + q0 * k, x->d_flags + q0);
+                               d_dist_out + q0 * k, x->d_flags + q0, ver);
         }
     }
     VQ_HIP(hipGetLastError());
@@ -227,6 +244,8 @@ int vq_index_create(int dim, vq_index** out) {
     VQ_CHECK(out && dim > 0 && dim % 4 == 0 && dim <= 4096, "vq_index_create: dim %d must be a positive multiple of 4", dim);
     vq_index* x = new vq_index();
     x->dim = dim;
+    if (const char* sv = getenv("VQ_AMD_SCAN")) x->scan_version = atoi(sv) == 1 ? 1 : 2;
+    if (dim % 128 != 0) x->scan_version = 1;
     hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete x; return fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     x->stream = x->own_stream;
