@@ -105,6 +105,9 @@ void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float NEG = -__builtin_inff();
+    // pad rows get a FINITE sentinel: -inf with index bits packed into its mantissa would be a signalling
+    // NaN, and v_max_f32 in IEEE mode turns (x, sNaN) into NaN, wiping the running maximum
+    const float MASKED = -3.0e38f;
     float m1[4] = {NEG, NEG, NEG, NEG}, m2[4] = {NEG, NEG, NEG, NEG};
 
     stage(0, 0);
@@ -141,7 +144,7 @@ void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __re
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[mi][ni][r];
-                        if (ragged && n0 + t * 128 + wn * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = NEG;
+                        if (ragged && n0 + t * 128 + wn * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = MASKED;
                         const uint32_t kb = (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)(t * 16 + ni * 4 + r);
                         const float kf = __builtin_bit_cast(float, kb);
                         m2[mi] = __builtin_amdgcn_fmed3f(m1[mi], m2[mi], kf);
@@ -242,6 +245,7 @@ void scan2_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     frag af[4][2], wf[2][2];
     const float NEG = -__builtin_inff();
+    const float MASKED = -3.0e38f;       // finite: see scan_f16_top2_kernel
     float m1[8], m2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { m1[i] = NEG; m2[i] = NEG; }
@@ -282,7 +286,7 @@ void scan2_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
                 for (int r = 0; r < 4; ++r) {
                     const int mi = hm * 4 + i, ni = hn * 2 + j;
                     float v = acc[mi][ni][r];
-                    if (ragged && n0 + t * 256 + wc * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = NEG;
+                    if (ragged && n0 + t * 256 + wc * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = MASKED;
                     const uint32_t kb = (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)(t * 16 + ni * 4 + r);
                     const float kf = __builtin_bit_cast(float, kb);
                     m2[mi] = __builtin_amdgcn_fmed3f(m1[mi], m2[mi], kf);
