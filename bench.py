@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per step per GPU (BASELINE config: 256)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: consecutive steps alternate between this many encoder "
                          "handles on separate HIP streams, so one batch's tail workgroups overlap the next batch")
     return ap.parse_args()

@@ -259,7 +259,7 @@ constexpr int G3_PART = 256 * G3_SUB_K * 2;       // 16 KiB: 256 rows x 64 B (on
 constexpr int G3_SLOT = 2 * G3_PART;              // 32 KiB
 constexpr int G3_LDS_BYTES = 4 * G3_SLOT;         // 128 KiB
 
-template <bool IS_F16, class Epi, bool DIAG = false>
+template <bool IS_F16, class Epi, bool DIAG = false, int NSLOT = 4>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
                             const uint16_t* __restrict__ W, int ldw,
@@ -317,7 +317,9 @@ void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
         asm volatile("" ::: "memory");
     };
 
-    auto phase = [&](int p, int slot) {
+    // NSLOT ring slots (4 = 128 KiB, 5 = 160 KiB): NSLOT-1 sub-tiles in flight while one is consumed.
+    // The slot index is wave-uniform run-time state (scalar adds), so the loop needs no unrolling.
+    auto phase = [&](int p, int slot, int slot_refill) __attribute__((always_inline)) {
         const char* buf = smem + slot * G3_SLOT;
         frag af[8], wf[4];
         if (DIAG && (diag & 2)) {
@@ -331,9 +333,10 @@ void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[j] = *(const frag*)(buf + w_base + j * 1024);
         }
-        if (p + 3 < nsub) {
-            if (!(DIAG && (diag & 1))) stage((slot + 3) & 3, p + 3);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (p + NSLOT - 1 < nsub) {
+            if (!(DIAG && (diag & 1))) stage(slot_refill, p + NSLOT - 1);
+            if constexpr (NSLOT == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else                      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -351,14 +354,19 @@ void gemm_tn256_ring_kernel(const uint16_t* __restrict__ A, int lda,
         if (!(DIAG && (diag & 8))) barrier();
     };
 
-    // prologue: sub-tiles 0,1,2 in flight, 0 landed
-    stage(0, 0); stage(1, 1); stage(2, 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // prologue: sub-tiles 0..NSLOT-2 in flight, 0 landed
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) stage(i, i);
+    if constexpr (NSLOT == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else                      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     barrier();
 
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
-    for (int p = 0; p < nsub; p += 4) {
-        phase(p, 0); phase(p + 1, 1); phase(p + 2, 2); phase(p + 3, 3);
+    int slot = 0, slot_refill = NSLOT - 1;
+    for (int p = 0; p < nsub; ++p) {
+        phase(p, slot, slot_refill);
+        slot_refill = slot;               // the slot just consumed is refilled next phase ... (p-1)%NSLOT
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
     if (wr == 0) barrier();
 
@@ -375,12 +383,12 @@ static int launch_gemm_tn256_ring(hipStream_t st, const uint16_t* A, int lda, co
              "gemm_tn256_ring: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
     static bool attr_set = false;
     if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi, false, 5>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 5 * G3_SLOT));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
-                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, 0);
+    hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi, false, 5>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                       5 * G3_SLOT, st, A, lda, W, ldw, K, N / G2_BN, epi, 0);
     VQ_HIP(hipGetLastError());
     return 0;
 }
@@ -389,10 +397,17 @@ template <bool IS_F16, class Epi>
 static int launch_gemm_tn256_ring_diag(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                                        int M, int N, int K, const Epi& epi, int diag) {
     VQ_CHECK(M % G2_BM == 0 && N % G2_BN == 0 && K % 128 == 0, "gemm_tn256_ring_diag: shape not tile-aligned");
-    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
-    hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi, true>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
-                       G3_LDS_BYTES, st, A, lda, W, ldw, K, N / G2_BN, epi, diag);
+    if (diag & 16) {      // bit4: 5-slot ring
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi, true, 5>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 5 * G3_SLOT));
+        hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi, true, 5>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                           5 * G3_SLOT, st, A, lda, W, ldw, K, N / G2_BN, epi, diag);
+    } else {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256_ring_kernel<IS_F16, Epi, true, 4>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_SLOT));
+        hipLaunchKernelGGL((gemm_tn256_ring_kernel<IS_F16, Epi, true, 4>), dim3((M / G2_BM) * (N / G2_BN)), dim3(G2_THREADS),
+                           4 * G3_SLOT, st, A, lda, W, ldw, K, N / G2_BN, epi, diag);
+    }
     VQ_HIP(hipGetLastError());
     return 0;
 }

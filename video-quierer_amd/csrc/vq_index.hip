@@ -182,9 +182,11 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
         {
             Prof p(x, I_MFMA_SCAN);
-            if (ver == 2)
-                hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(q_tiles * ranges), dim3(G2_THREADS), G2_LDS_BYTES, x->stream,
-                                   x->d_q16, x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
+            if (ver == 2) {
+                const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
+                hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), G2_LDS_BYTES,
+                                   x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
+            }
             else
                 hipLaunchKernelGGL(scan_f16_top2_kernel, dim3(q_tiles * ranges), dim3(GEMM_THREADS), 0, x->stream, x->d_q16,
                                    x->rows16, x->dim, n, q_tiles, q_pad, x->d_keys);
