@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--search-queries", type=int, default=10_000)
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=64)
+    ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (~15 s of host work)")
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per step per GPU (BASELINE config: 256)")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: consecutive steps alternate between this many encoder "
@@ -153,10 +153,19 @@ def main():
         rows = BATCH * cfg.tokens
         fl = gemm_flops(dom, rows, cfg)
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
+        # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
+        # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/, gfx950 correction applied there)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
+        except OSError:
+            pass
         if fl is not None:
             ach = fl / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12,
-                               "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_BF16, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_BF16, "traffic": traffic,
+                               "traffic_source": "profiles/r01b_pmc_traffic.json (rocprofv3 PMC, batch 256)",
                                "avg_launch_ms": avg_ms, "flops_per_launch": fl}
         else:
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",

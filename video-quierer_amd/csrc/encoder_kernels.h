@@ -338,27 +338,28 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 // ============================ pooling head ===================================
 // CLS token -> post_layernorm -> visual_projection (fp32 weights, no bias) ->
 // L2 normalise (x / max(||x||, 1e-12), F.normalize)                 (E8-E10)
-// One 256-thread workgroup per POOL_IMGS images.  Each wave LayerNorms two CLS rows
-// into LDS; then thread t owns outputs t and t+256 for all POOL_IMGS images and walks
-// k: the projection is stored TRANSPOSED [hidden][proj_dim] so the weight reads are
-// coalesced across threads and shared by the images; the normalised rows are LDS
-// broadcasts.  proj_dim <= 512.
+// Two launches.  pool_project_kernel: workgroup (image group of 8, output chunk of 64); each wave
+// LayerNorms two CLS rows into LDS, then thread (o = tid & 63, pair = tid >> 6) accumulates output
+// chunk*64 + o for images 2*pair, 2*pair+1 over k; the projection is stored TRANSPOSED
+// [hidden][proj_dim] so the 64 threads of a wave read 256 contiguous bytes per k.
+// l2_normalize_rows_kernel: one wave per image.
 constexpr int POOL_IMGS = 8;
+constexpr int POOL_CHUNK = 64;
 template <int NV>
 __global__ __launch_bounds__(256)
 void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ g,
                          const float* __restrict__ b, const float* __restrict__ wproj_t,
-                         float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
+                         float* __restrict__ feat /*[n][proj_dim], un-normalised*/,
                          int n_images, int tokens, int proj_dim, float eps) {
     constexpr int H = NV * 256;
     __shared__ __attribute__((aligned(16))) float xn[POOL_IMGS][H];
-    __shared__ float red[POOL_IMGS][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img0 = blockIdx.x * POOL_IMGS;
+    const int o = blockIdx.y * POOL_CHUNK + lane;
 #pragma unroll
-    for (int j = 0; j < POOL_IMGS / 4; ++j) {
-        const int im = wave * (POOL_IMGS / 4) + j;
-        const int img = min(img0 + im, n_images - 1);            // tail workgroup: duplicate the last image
+    for (int j = 0; j < 2; ++j) {
+        const int im = wave * 2 + j;
+        const int img = min(img0 + im, n_images - 1);            // tail group: duplicate the last image
         float4 v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
@@ -367,49 +368,38 @@ void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ 
         for (int i = 0; i < NV; ++i) *(float4*)(&xn[im][(i * 64 + lane) * 4]) = v[i];
     }
     __syncthreads();
-    float acc[2][POOL_IMGS];
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int im = 0; im < POOL_IMGS; ++im) acc[o][im] = 0.f;
-    const int o0 = tid, o1 = tid + 256;
-    const bool has0 = o0 < proj_dim, has1 = o1 < proj_dim;
+    const bool live = o < proj_dim;
+    const float* wcol = wproj_t + (live ? o : 0);
+    const float* x0 = xn[wave * 2], *x1 = xn[wave * 2 + 1];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
     for (int k = 0; k < H; k += 4) {
-        float w0[4], w1[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            w0[kk] = has0 ? wproj_t[(size_t)(k + kk) * proj_dim + o0] : 0.f;
-            w1[kk] = has1 ? wproj_t[(size_t)(k + kk) * proj_dim + o1] : 0.f;
-        }
-#pragma unroll
-        for (int im = 0; im < POOL_IMGS; ++im) {
-            const float4 xv = *(const float4*)(&xn[im][k]);      // same address in every lane: broadcast
-            acc[0][im] += xv.x * w0[0]; acc[0][im] += xv.y * w0[1]; acc[0][im] += xv.z * w0[2]; acc[0][im] += xv.w * w0[3];
-            acc[1][im] += xv.x * w1[0]; acc[1][im] += xv.y * w1[1]; acc[1][im] += xv.z * w1[2]; acc[1][im] += xv.w * w1[3];
-        }
+        const float w0 = wcol[(size_t)(k + 0) * proj_dim], w1 = wcol[(size_t)(k + 1) * proj_dim];
+        const float w2 = wcol[(size_t)(k + 2) * proj_dim], w3 = wcol[(size_t)(k + 3) * proj_dim];
+        const float4 u = *(const float4*)(x0 + k), v = *(const float4*)(x1 + k);      // LDS broadcasts
+        a0 += u.x * w0; a0 += u.y * w1; a0 += u.z * w2; a0 += u.w * w3;
+        a1 += v.x * w0; a1 += v.y * w1; a1 += v.z * w2; a1 += v.w * w3;
     }
-#pragma unroll
-    for (int im = 0; im < POOL_IMGS; ++im) {
-        const float s = wave_sum(acc[0][im] * acc[0][im] + acc[1][im] * acc[1][im]);
-        if (lane == 0) red[im][wave] = s;
+    if (live) {
+        const int i0 = img0 + wave * 2, i1 = i0 + 1;
+        if (i0 < n_images) feat[(size_t)i0 * proj_dim + o] = a0;
+        if (i1 < n_images) feat[(size_t)i1 * proj_dim + o] = a1;
     }
-    __syncthreads();
-#pragma unroll
-    for (int im = 0; im < POOL_IMGS; ++im) {
-        const int img = img0 + im;
-        if (img < n_images) {
-            const float nrm = fmaxf(sqrtf((red[im][0] + red[im][1]) + (red[im][2] + red[im][3])), 1e-12f);
-            if (has0) {
-                const float e = acc[0][im] / nrm;
-                out_f32[(size_t)img * proj_dim + o0] = e;
-                if (out_f16) out_f16[(size_t)img * proj_dim + o0] = __builtin_bit_cast(uint16_t, (_Float16)e);
-            }
-            if (has1) {
-                const float e = acc[1][im] / nrm;
-                out_f32[(size_t)img * proj_dim + o1] = e;
-                if (out_f16) out_f16[(size_t)img * proj_dim + o1] = __builtin_bit_cast(uint16_t, (_Float16)e);
-            }
-        }
+}
+
+__global__ __launch_bounds__(256)
+void l2_normalize_rows_kernel(float* __restrict__ feat, uint16_t* __restrict__ out_f16, int n_images, int proj_dim) {
+    const int lane = threadIdx.x & 63;
+    const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (img >= n_images) return;
+    float* row = feat + (size_t)img * proj_dim;
+    float ss = 0.f;
+    for (int i = lane; i < proj_dim; i += 64) ss += row[i] * row[i];
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int i = lane; i < proj_dim; i += 64) {
+        const float e = row[i] / nrm;
+        row[i] = e;
+        if (out_f16) out_f16[(size_t)img * proj_dim + i] = __builtin_bit_cast(uint16_t, (_Float16)e);
     }
 }
 

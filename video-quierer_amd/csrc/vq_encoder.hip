@@ -190,8 +190,9 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     }
     {   // E8-E10
         Prof p(e, C_POOL);
-        hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(cdiv(n, POOL_IMGS)), dim3(256), 0, st, e->x, e->post_g, e->post_b,
-                           e->w_proj, d_out_f32, d_out_f16, n, T, c.proj_dim, c.ln_eps);
+        hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(cdiv(n, POOL_IMGS), cdiv(c.proj_dim, POOL_CHUNK)), dim3(256), 0, st,
+                           e->x, e->post_g, e->post_b, e->w_proj, d_out_f32, n, T, c.proj_dim, c.ln_eps);
+        hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, d_out_f32, d_out_f16, n, c.proj_dim);
     }
     VQ_HIP(hipGetLastError());
     e->last_n = n;
@@ -227,7 +228,7 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
     VQ_CHECK(c.heads % 4 == 0, "vq_encoder_create: heads must be a multiple of 4");
     VQ_CHECK((c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0, "vq_encoder_create: hidden %d / mlp %d unsupported",
              c.hidden, c.mlp);
-    VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 512, "vq_encoder_create: proj_dim %d out of range (<= 512)", c.proj_dim);
+    VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 4096, "vq_encoder_create: proj_dim %d out of range", c.proj_dim);
     const int patch_k_raw = 3 * c.patch_size * c.patch_size;
     const int patch_k = (int)round_up(patch_k_raw, GEMM_BK);
     VQ_CHECK(patch_k == patch_k_raw, "vq_encoder_create: patch K %d must be a multiple of 64", patch_k_raw);
