@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (~15 s of host work)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="GEMM operand type (BASELINE config: bf16)")
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per step per GPU (BASELINE config: 256)")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: consecutive steps alternate between this many encoder "
@@ -87,7 +88,7 @@ def main():
     # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local) for _ in range(nstreams)]
+    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype) for _ in range(nstreams)]
     for e_, s_ in zip(encs, streams):
         e_.set_stream(s_.cuda_stream)
     enc, stream = encs[0], streams[0]
@@ -132,7 +133,7 @@ def main():
     out = {
         "metric": METRIC, "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: batch-256 ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
                                "device-resident input (H2D excluded), seeded random-init weights",
                    "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,

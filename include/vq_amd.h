@@ -67,6 +67,11 @@ typedef struct vq_vit_config {
  * max_batch: frames per device pass (workspace is sized for it). */
 int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int n_weights,
                       int max_batch, vq_encoder** out);
+/* Same with flags: VQ_ENC_FP16 = fp16 instead of bf16 GEMM operands (same MFMA rate, ~8x smaller
+ * rounding error; the type ViT-L/14@336 is specified with).  $VQ_AMD_DTYPE=fp16|bf16 overrides. */
+#define VQ_ENC_FP16 1
+int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, int n_weights,
+                         int max_batch, int flags, vq_encoder** out);
 int vq_encoder_destroy(vq_encoder* enc);
 
 /* extract_batch (feature_extractor.py:137-177) for uint8 frames already at

@@ -101,6 +101,22 @@ def test_encoder_matches_golden_embeddings(encoder, golden_encoder):
     print(f"encoder vs golden: min cos {cos.min():.7f}, score diff rms {np.sqrt((diff**2).mean()):.2e} max {diff.max():.2e}")
 
 
+def test_encoder_fp16_operands_are_8x_closer(gpu_lib, b32_weights, golden_encoder):
+    """compute_dtype="fp16": same kernels instantiated for fp16 MFMA operands (what ViT-L/14@336 is specified
+    with); the embedding error drops from ~5e-3 (bf16) to <1e-3 in L2 and every pairwise score is within 3e-4."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    enc = VitEncoder(VIT_B_32, b32_weights, max_batch=64, compute_dtype="fp16")
+    emb = enc.encode(synth_frames(64))
+    enc.close()
+    err = np.linalg.norm(emb - golden_encoder["embeddings"], axis=1)
+    assert err.max() <= 1.5e-3, err.max()
+    rows = knn_oracle.normalize_rows(np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32))
+    diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
+    assert diff.max() <= 3e-4
+    print(f"fp16 operands: max L2 err {err.max():.2e}, max score diff {diff.max():.2e}")
+
+
 def test_encoder_batch_shapes_and_paths(encoder, b32_weights):
     frames = synth_frames(70, seed=3)                 # > max_batch=64: two device passes, ragged tail of 6
     full = encoder.encode(frames)

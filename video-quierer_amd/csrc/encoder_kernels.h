@@ -3,37 +3,54 @@
 // pooling head.  gfx950 only.  Row references are to SURVEY.md §8a (E-rows).
 #pragma once
 #include "vq_common.h"
+#include "gemm_mfma.h"
 
 namespace vq {
 
 // ============================ GEMM epilogues =================================
 // Each is called with (m, n, v) where v = C[m][n..n+3] (fp32 accumulators).
 
-__device__ __forceinline__ uint2 pack4_bf16(f32x4 v) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32 (RNE)
-    return __builtin_bit_cast(uint2, b);
+// F16 = false: bf16 GEMM operands (the BASELINE config); true: fp16 operands (same MFMA rate, 8x
+// smaller rounding error; what ViT-L/14@336 is specified with).
+template <bool F16>
+__device__ __forceinline__ uint2 pack4_h(f32x4 v) {
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        h4 b = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        return __builtin_bit_cast(uint2, b);
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32 (RNE)
+        return __builtin_bit_cast(uint2, b);
+    }
+}
+template <bool F16>
+__host__ __device__ inline uint16_t to_h16(float f) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)f);
+    else return f32_to_bf16_rne(f);
 }
 
-// y = acc + bias  -> bf16                      (E6: fused q|k|v projection)
-struct EpiBiasBf16 {
+// y = acc + bias  -> 16-bit                    (E6: fused q|k|v projection)
+template <bool F16>
+struct EpiBiasH16 {
     uint16_t* out; int ldo; const float* bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         const float4 b = *(const float4*)(bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        *(uint2*)(out + (size_t)m * ldo + n) = pack4_bf16(v);
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
     }
 };
 
-// y = quick_gelu(acc + bias) -> bf16           (E7: fc1; x*sigmoid(1.702x))
-struct EpiBiasQuickGeluBf16 {
+// y = quick_gelu(acc + bias) -> 16-bit         (E7: fc1; x*sigmoid(1.702x))
+template <bool F16>
+struct EpiBiasQuickGeluH16 {
     uint16_t* out; int ldo; const float* bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         const float4 b = *(const float4*)(bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
-        *(uint2*)(out + (size_t)m * ldo + n) = pack4_bf16(v);
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
     }
 };
 
@@ -71,6 +88,7 @@ struct EpiPatchEmbedF32 {
 // swap_rb=1 reverses the channel axis (cv2.COLOR_BGR2RGB for ndarray input, E1).
 // One thread handles 8 consecutive pixels of one image row (24 contiguous bytes)
 // and writes three 16-byte runs, one per channel plane.  Requires ps % 8 == 0.
+template <bool F16>
 __global__ __launch_bounds__(256)
 void patchify_u8_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ out,
                         int n, int S, int ps, int swap_rb) {
@@ -98,7 +116,7 @@ void patchify_u8_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict
             for (int i = 0; i < 8; ++i) {
                 const int byte = i * 3 + cs;
                 const int px = (w[byte >> 2] >> ((byte & 3) * 8)) & 0xff;
-                v[i] = f32_to_bf16_rne((float)(px - 128));
+                v[i] = to_h16<F16>((float)(px - 128));
             }
             uint4 o = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
                        (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
@@ -141,7 +159,7 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], const float* __restrict_
 }
 
 // h = LN(x) as bf16 (LN1 / LN2 feeding the next GEMM)
-template <int NV>
+template <int NV, bool F16>
 __global__ __launch_bounds__(256)
 void layernorm_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ h,
                            const float* __restrict__ g, const float* __restrict__ b,
@@ -156,13 +174,13 @@ void layernorm_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ h
     ln_row<NV>(v, g, b, lane, eps, H);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_bf16(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
 }
 
 // Embedding finish (E3 tail + E4 + first LN1): token 0 of every image is
 // class_embedding + position_embedding[0]; then x = pre_layrnorm(x) in place
 // (fp32 residual stream) and h = layer_norm1[layer 0](x) as bf16.
-template <int NV>
+template <int NV, bool F16>
 __global__ __launch_bounds__(256)
 void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
                          const float* __restrict__ cls, const float* __restrict__ pos0,
@@ -191,7 +209,7 @@ void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
     ln_row<NV>(v, g_ln1, b_ln1, lane, eps, H);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_bf16(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
 }
 
 // ============================ attention ======================================
@@ -204,6 +222,7 @@ void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
 //                   key(s,g,j) = 32 s + 16 (j>>2) + 4 g + (j&3); V^T fragments in that same
 //                   order come from ds_read_b64_tr_b16 on a row-major [64 keys][64 d] LDS tile.
 // qkv: [rows][3*hidden] bf16 (q | k | v);  out: [rows][hidden] bf16.
+template <bool F16>
 __global__ __launch_bounds__(256)
 void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                           int tokens, int hidden, int heads) {
@@ -216,6 +235,8 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     const int ld = 3 * hidden;
     const uint16_t* base = qkv + (size_t)img * tokens * ld + head * 64;
     const int r16 = lane & 15, g = lane >> 4;
+    typedef mfma_op<F16> op;
+    typedef typename op::frag frag;
 
     // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
     uint16_t* vt = vlds[wave];
@@ -228,7 +249,7 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     }
 
     // K (A operand) and Q (B operand) fragments straight from global memory
-    bf16x8 kf[4][2], qf[4][2];
+    frag kf[4][2], qf[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = t * 16 + r16;
@@ -239,8 +260,8 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 kv = *(const uint4*)(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
                 qv = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
             }
-            kf[t][ks] = __builtin_bit_cast(bf16x8, kv);
-            qf[t][ks] = __builtin_bit_cast(bf16x8, qv);
+            kf[t][ks] = __builtin_bit_cast(frag, kv);
+            qf[t][ks] = __builtin_bit_cast(frag, qv);
         }
     }
 
@@ -251,8 +272,8 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt][0], qf[nt][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt][1], qf[nt][1], a, 0, 0, 0);
+            a = op::run(kf[mt][0], qf[nt][0], a);
+            a = op::run(kf[mt][1], qf[nt][1], a);
             s[mt][nt] = a;
         }
 
@@ -286,14 +307,14 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     }
 
     // P^T fragments (B operand): k-slot j<4 -> tile 2s reg j ; j>=4 -> tile 2s+1 reg j-4
-    bf16x8 pf[4][2];
+    frag pf[4][2];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const f32x4 lo = s[2 * ss][nt], hi = s[2 * ss + 1][nt];
-            pf[nt][ss] = bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3],
-                                (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+            const uint2 plo = pack4_h<F16>(lo), phi = pack4_h<F16>(hi);
+            pf[nt][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
         }
 
     __syncthreads();   // V tile visible (all 64 lanes active from here on: tr reads need full EXEC)
@@ -316,10 +337,10 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 (lds_s16x4*)(vt + (key0 + 16) * 64 + dt * 16 + p4 * 4));
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+            const frag vf = __builtin_bit_cast(frag, both);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[nt][ss], o[nt], 0, 0, 0);
+                o[nt] = op::run(vf, pf[nt][ss], o[nt]);
         }
         // O^T: lane holds d = 16 dt + 4 g + r, query 16 nt + r16
 #pragma unroll
@@ -329,7 +350,7 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 f32x4 v = o[nt];
                 v[0] *= inv_sum[nt]; v[1] *= inv_sum[nt]; v[2] *= inv_sum[nt]; v[3] *= inv_sum[nt];
                 *(uint2*)(out + ((size_t)img * tokens + qrow) * hidden + head * 64 + dt * 16 + g * 4) =
-                    pack4_bf16(v);
+                    pack4_h<F16>(v);
             }
         }
     }

@@ -60,6 +60,7 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     int run_layers = -1;
     int last_n = 0;
+    bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles
     // profiling
     bool profiling = false;
@@ -108,14 +109,15 @@ int upload_f32(float* dst, const float* src, size_t n) {
     VQ_HIP(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice));
     return 0;
 }
-int upload_bf16(uint16_t* dst, const float* src, size_t n, float scale = 1.0f) {
+int upload_h16(uint16_t* dst, const float* src, size_t n, bool f16, float scale = 1.0f) {
     std::vector<uint16_t> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_rne(src[i] * scale);
+    if (f16) for (size_t i = 0; i < n; ++i) tmp[i] = __builtin_bit_cast(uint16_t, (_Float16)(src[i] * scale));
+    else     for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_rne(src[i] * scale);
     VQ_HIP(hipMemcpy(dst, tmp.data(), n * 2, hipMemcpyHostToDevice));
     return 0;
 }
 
-template <int NV>
+template <int NV, bool F16>
 int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
     const vq_vit_config& c = e->cfg;
     hipStream_t st = e->stream;
@@ -135,56 +137,56 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         Prof p(e, C_PATCHIFY);
         const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
         const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(patchify_u8_kernel, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+        hipLaunchKernelGGL(patchify_u8_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
                            c.image_size, c.patch_size, swap_rb);
     }
     {   // E3: patch-embedding conv as a GEMM, epilogue scatters into token rows + position embedding
         Prof p(e, C_GEMM_PATCH);
-        VQ_TRY((launch_gemm_auto<false>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
+        VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
                                         EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force)));
     }
     const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
     {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
         Prof p(e, C_EMBED_FINISH);
         const LayerW& L0 = e->layers[0];
-        hipLaunchKernelGGL((embed_finish_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
+        hipLaunchKernelGGL((embed_finish_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
                            e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
     }
     for (int l = 0; l < nl; ++l) {
         const LayerW& L = e->layers[l];
         if (l > 0) {
             Prof p(e, C_LAYERNORM);
-            hipLaunchKernelGGL((layernorm_bf16_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
+            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
                                L.ln1_g, L.ln1_b, rows, c.ln_eps);
         }
         {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
             Prof p(e, C_GEMM_QKV);
-            VQ_TRY((launch_gemm_auto<false>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
-                                            EpiBiasBf16{e->qkv, 3 * H, L.b_qkv}, e->gemm_force)));
+            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
+                                            EpiBiasH16<F16>{e->qkv, 3 * H, L.b_qkv}, e->gemm_force)));
         }
         {
             Prof p(e, C_ATTENTION);
-            hipLaunchKernelGGL(attention_t64_kernel, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
+            hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
                                c.heads);
         }
         {
             Prof p(e, C_GEMM_OUT);
-            VQ_TRY((launch_gemm_auto<false>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
                                             EpiBiasResidualF32{e->x, H, L.b_out}, e->gemm_force)));
         }
         {
             Prof p(e, C_LAYERNORM);
-            hipLaunchKernelGGL((layernorm_bf16_kernel<NV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
+            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
                                L.ln2_g, L.ln2_b, rows, c.ln_eps);
         }
         {   // E7: fc1 + quick_gelu
             Prof p(e, C_GEMM_FC1);
-            VQ_TRY((launch_gemm_auto<false>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
-                                            EpiBiasQuickGeluBf16{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
+            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
+                                            EpiBiasQuickGeluH16<F16>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
         }
         {
             Prof p(e, C_GEMM_FC2);
-            VQ_TRY((launch_gemm_auto<false>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
                                             EpiBiasResidualF32{e->x, H, L.b_fc2}, e->gemm_force)));
         }
     }
@@ -200,9 +202,12 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
 }
 
 int forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
-    switch (e->cfg.hidden / 256) {
-        case 3: return run_forward<3>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
-        case 4: return run_forward<4>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+    const int key = (e->cfg.hidden / 256) * 2 + (e->fp16 ? 1 : 0);
+    switch (key) {
+        case 6: return run_forward<3, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        case 7: return run_forward<3, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        case 8: return run_forward<4, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        case 9: return run_forward<4, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
         default: return fail(VQ_ERR_INVALID, "unsupported hidden size %d", e->cfg.hidden);
     }
 }
@@ -213,6 +218,11 @@ extern "C" {
 
 int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int n_weights, int max_batch,
                       vq_encoder** out) {
+    return vq_encoder_create_ex(cfg, weights, n_weights, max_batch, 0, out);
+}
+
+int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, int n_weights, int max_batch,
+                         int flags, vq_encoder** out) {
     VQ_TRY(require_init());
     VQ_CHECK(cfg && weights && out, "vq_encoder_create: null argument");
     const vq_vit_config c = *cfg;
@@ -235,6 +245,8 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
 
     vq_encoder* e = new vq_encoder();
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    e->fp16 = (flags & VQ_ENC_FP16) != 0;
+    if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
     e->rows_pad = round_up((int64_t)max_batch * tokens, 256);
     e->prow_pad = round_up((int64_t)max_batch * patches, 256);
@@ -270,7 +282,8 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
             for (int ch = 0; ch < 3; ++ch)
                 for (int i = 0; i < pp; ++i) {
                     const double w = wp[(n * 3 + ch) * pp + i];
-                    w16[n * patch_k + ch * pp + i] = f32_to_bf16_rne((float)(w / (255.0 * stdv[ch])));
+                    w16[n * patch_k + ch * pp + i] = e->fp16 ? __builtin_bit_cast(uint16_t, (_Float16)(float)(w / (255.0 * stdv[ch])))
+                                                             : f32_to_bf16_rne((float)(w / (255.0 * stdv[ch])));
                     b += w * (128.0 / 255.0 - mean[ch]) / stdv[ch];
                 }
             bias[n] = (float)b;
@@ -293,18 +306,18 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
         L.b_qkv = A.take<float>(3 * H);
         for (int part = 0; part < 3; ++part) {        // q, k, v
             const float s = part == 0 ? qscale : 1.0f;
-            UP(upload_bf16(L.w_qkv + part * H * H, weights[wi++], H * H, s));
+            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->fp16, s));
             std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
             for (auto& v : b) v *= s;
             UP(upload_f32(L.b_qkv + part * H, b.data(), H));
         }
-        L.w_out = A.take<uint16_t>(H * H);    UP(upload_bf16(L.w_out, weights[wi++], H * H));
+        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->fp16));
         L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
         L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
         L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
-        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_bf16(L.w_fc1, weights[wi++], M * H));
+        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->fp16));
         L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
-        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_bf16(L.w_fc2, weights[wi++], H * M));
+        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->fp16));
         L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
     }
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));
@@ -441,7 +454,8 @@ int vq_encoder_debug_read(vq_encoder* e, const char* name, int rows, float* out)
     else return fail(VQ_ERR_INVALID, "vq_encoder_debug_read: unknown buffer '%s'", name);
     std::vector<uint16_t> tmp((size_t)rows * cols);
     VQ_HIP(hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < tmp.size(); ++i) out[i] = bf16_to_f32(tmp[i]);
+    for (size_t i = 0; i < tmp.size(); ++i)
+        out[i] = e->fp16 ? (float)__builtin_bit_cast(_Float16, tmp[i]) : bf16_to_f32(tmp[i]);
     return 0;
 }
 
