@@ -354,3 +354,33 @@ def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
     st = _scan_vs_oracle(same, same[:3] + 0, 5)
     print("fp16 scan, all-identical rows:", st)
     assert st["exact_fallback"] == 3
+
+
+# ------------------------------------------------------------------ live system's brute-force index ("next" #2)
+def test_simple_video_index_matches_reference_semantics(gpu_lib, tmp_path):
+    from video_quierer_amd.overhaul_index import SimpleVideoIndex
+    rng = np.random.default_rng(77)
+    emb = rng.standard_normal((300, 512)).astype(np.float32)
+    emb[:200] /= np.linalg.norm(emb[:200], axis=1, keepdims=True)      # the last 100 rows stay un-normalised
+    emb[250] = emb[7]                                                    # exact duplicate → tie
+    idx = SimpleVideoIndex()
+    assert idx.search(emb[0], 3) == []
+    for i, e in enumerate(emb):
+        idx.add_frame(e, f"video_{i // 100}.mp4", i * 0.5)
+    for qi in (0, 7, 123, 260):
+        q = emb[qi] * 2.5
+        got = idx.search(q, 5)
+        # restatement of video_search_overhaul.py:40-64
+        sims = emb @ (q / (np.linalg.norm(q) + 1e-10))
+        want = np.argsort(sims, kind="stable")[::-1][:5]
+        assert [g["frame_id"] for g in got] == [int(w) for w in want]
+        assert np.allclose([g["score"] for g in got], sims[want], atol=2e-6)
+        assert set(got[0]) == {"video_name", "timestamp", "frame_id", "score"} and isinstance(got[0]["score"], float)
+    assert [g["frame_id"] for g in idx.search(emb[7], 2)] == [250, 7]      # tie → larger frame id first
+    path = tmp_path / "cache.pkl"
+    assert idx.save_to_disk(path)
+    fresh = SimpleVideoIndex()
+    assert fresh.load_from_disk(path) and not fresh.load_from_disk(tmp_path / "missing.pkl")
+    assert [g["frame_id"] for g in fresh.search(emb[123], 5)] == [g["frame_id"] for g in idx.search(emb[123], 5)]
+    idx.add_frame(emb[123] * 3, "late.mp4", 1.0)                         # incremental add after a search
+    assert idx.search(emb[123], 1)[0]["frame_id"] == 300
