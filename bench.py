@@ -187,6 +187,7 @@ def main():
         for c0 in range(0, n_rows, 250_000):
             c = min(250_000, n_rows - c0)
             block = torch.randn((c, 512), dtype=torch.float32, device=dev, generator=g2)
+            torch.cuda.synchronize(dev)                         # generated on torch's default stream, consumed on `stream`
             idx.add_device(block.data_ptr(), c, range(c0, c0 + c), normalize=True)
             torch.cuda.synchronize(dev)
         g3 = torch.Generator(device=dev)
@@ -195,19 +196,15 @@ def main():
         q = q / q.norm(dim=1, keepdim=True)
         ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
         dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        all_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev) if world > 1 else None
-        all_dd = torch.empty((world, nq, k), dtype=torch.float32, device=dev) if world > 1 else None
+        torch.cuda.synchronize(dev)
+
+        from video_quierer_amd.distributed import sharded_topk
 
         def search_step():
-            idx.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
-            if world > 1:       # exchange step: all-gather of local top-k, merged with the same (distance,id) order
-                dist.all_gather_into_tensor(all_ids, ids + rank * n_rows)
-                dist.all_gather_into_tensor(all_dd, dd)
-                cat_d = all_dd.permute(1, 0, 2).reshape(nq, world * k)
-                cat_i = all_ids.permute(1, 0, 2).reshape(nq, world * k)
-                order = torch.argsort(cat_d, dim=1, stable=True)[:, :k]   # rank-major concat => ties keep the smaller global id
-                return torch.gather(cat_i, 1, order), torch.gather(cat_d, 1, order)
-            return ids, dd
+            with torch.cuda.stream(stream):     # the index runs on `stream`; keep the torch/RCCL ops on it too
+                idx.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
+                # exchange step (N>1): all-gather of the local top-k with global row ids + (distance,id) merge
+                return sharded_topk(ids, dd, rank * n_rows, k)
 
         search_step()
         fence()

@@ -362,12 +362,12 @@ def test_simple_video_index_matches_reference_semantics(gpu_lib, tmp_path):
     rng = np.random.default_rng(77)
     emb = rng.standard_normal((300, 512)).astype(np.float32)
     emb[:200] /= np.linalg.norm(emb[:200], axis=1, keepdims=True)      # the last 100 rows stay un-normalised
-    emb[250] = emb[7]                                                    # exact duplicate → tie
+    emb[250] = emb[230]                                                  # exact duplicate → tie
     idx = SimpleVideoIndex()
     assert idx.search(emb[0], 3) == []
     for i, e in enumerate(emb):
         idx.add_frame(e, f"video_{i // 100}.mp4", i * 0.5)
-    for qi in (0, 7, 123, 260):
+    for qi in (0, 7, 123, 230, 260):
         q = emb[qi] * 2.5
         got = idx.search(q, 5)
         # restatement of video_search_overhaul.py:40-64
@@ -376,7 +376,7 @@ def test_simple_video_index_matches_reference_semantics(gpu_lib, tmp_path):
         assert [g["frame_id"] for g in got] == [int(w) for w in want]
         assert np.allclose([g["score"] for g in got], sims[want], atol=2e-6)
         assert set(got[0]) == {"video_name", "timestamp", "frame_id", "score"} and isinstance(got[0]["score"], float)
-    assert [g["frame_id"] for g in idx.search(emb[7], 2)] == [250, 7]      # tie → larger frame id first
+    assert [g["frame_id"] for g in idx.search(emb[230], 2)] == [250, 230]  # tie → larger frame id first
     path = tmp_path / "cache.pkl"
     assert idx.save_to_disk(path)
     fresh = SimpleVideoIndex()
