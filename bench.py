@@ -139,6 +139,10 @@ def main():
                    "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,
                    "parallelism": f"dp{world} (frame shards; RCCL all-gather of embeddings per step)" if world > 1 else "single GPU"},
         "encode_mfma_frac_whole_pass": frames_per_s / world * FLOP_PER_FRAME / PEAK_BF16,
+        # the last block's out_proj/LN2/MLP run on the CLS rows only (outputs identical): executed work per frame
+        "flop_per_frame": {"algorithmic": FLOP_PER_FRAME,
+                           "executed": FLOP_PER_FRAME - (0 if os.environ.get("VQ_AMD_FULL_LAST_LAYER") == "1"
+                                                         else 2 * 49 * (768 * 768 + 2 * 768 * 3072))},
     }
 
     if rank == 0:

@@ -66,6 +66,19 @@ struct EpiBiasResidualF32 {
     }
 };
 
+// Last block, CLS rows only: GEMM row m = image m -> residual row m*tokens; rows >= m_valid are padding
+struct EpiBiasResidualClsF32 {
+    float* x; int hidden; int tokens; const float* bias; int m_valid;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        if (m >= m_valid) return;
+        const float4 b = *(const float4*)(bias + n);
+        float4* p = (float4*)(x + (size_t)m * tokens * hidden + n);
+        float4 r = *p;
+        r.x += v[0] + b.x; r.y += v[1] + b.y; r.z += v[2] + b.z; r.w += v[3] + b.w;
+        *p = r;
+    }
+};
+
 // Patch-embedding GEMM: GEMM row m = (image b, patch p) -> token row b*T + 1 + p;
 // x = acc + folded_bias + position_embedding[1+p]          (E3)
 struct EpiPatchEmbedF32 {
@@ -158,19 +171,20 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], const float* __restrict_
     }
 }
 
-// h = LN(x) as bf16 (LN1 / LN2 feeding the next GEMM)
+// h = LN(x) as 16-bit (LN1 / LN2 feeding the next GEMM).  in_row_stride (in rows of x) lets the last
+// block normalise only the CLS rows (stride = tokens) into a compact h.
 template <int NV, bool F16>
 __global__ __launch_bounds__(256)
 void layernorm_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ h,
                            const float* __restrict__ g, const float* __restrict__ b,
-                           int rows, float eps) {
+                           int rows, float eps, int in_row_stride = 1) {
     constexpr int H = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float4 v[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)row * H + (i * 64 + lane) * 4);
+    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)row * in_row_stride * H + (i * 64 + lane) * 4);
     ln_row<NV>(v, g, b, lane, eps, H);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -210,6 +224,16 @@ void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+}
+
+// rows r*stride of a 16-bit [.][cols] matrix -> compact rows r (CLS gather for the last block)
+__global__ __launch_bounds__(256)
+void gather_rows_h16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int rows, int cols, int stride) {
+    const int per_row = cols / 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * per_row; i += gridDim.x * blockDim.x) {
+        const int r = i / per_row, c = i - r * per_row;
+        *(uint4*)(dst + (size_t)r * cols + c * 8) = *(const uint4*)(src + (size_t)r * stride * cols + c * 8);
+    }
 }
 
 // ============================ attention ======================================

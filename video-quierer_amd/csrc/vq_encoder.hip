@@ -60,6 +60,7 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     int run_layers = -1;
     int last_n = 0;
+    bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles
     // profiling
@@ -169,6 +170,35 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
             hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
                                c.heads);
         }
+        // Only the CLS token of the last block is consumed (E8): its out_proj / LN2 / MLP run on the
+        // n CLS rows instead of n*T rows (292.8 MMAC of 4408.8 per frame).  K/V and the
+        // attention itself still cover every token.  $VQ_AMD_FULL_LAST_LAYER=1 disables the pruning.
+        const bool cls_only = e->prune_last && e->run_layers < 0 && l == c.layers - 1;   // debug runs keep every row
+        if (cls_only) {
+            const int crows = pad_rows(n);
+            {
+                Prof p(e, C_GEMM_OUT);
+                hipLaunchKernelGGL(gather_rows_h16_kernel, dim3(cdiv(n * (H / 8), 256)), dim3(256), 0, st, e->att, e->h, n, H, T);
+                VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_out, H, crows, H, H,
+                                              EpiBiasResidualClsF32{e->x, H, T, L.b_out, n}, e->gemm_force)));
+            }
+            {
+                Prof p(e, C_LAYERNORM);
+                hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(n, 4)), dim3(256), 0, st, e->x, e->att,
+                                   L.ln2_g, L.ln2_b, n, c.ln_eps, T);
+            }
+            {
+                Prof p(e, C_GEMM_FC1);
+                VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_fc1, H, crows, c.mlp, H,
+                                              EpiBiasQuickGeluH16<F16>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
+            }
+            {
+                Prof p(e, C_GEMM_FC2);
+                VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp,
+                                              EpiBiasResidualClsF32{e->x, H, T, L.b_fc2, n}, e->gemm_force)));
+            }
+            continue;
+        }
         {
             Prof p(e, C_GEMM_OUT);
             VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
@@ -245,6 +275,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
 
     vq_encoder* e = new vq_encoder();
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->fp16 = (flags & VQ_ENC_FP16) != 0;
     if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
