@@ -17,7 +17,7 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-@pytest.mark.parametrize("kernel", [1, 2, 3])       # 1 = 128x128 two-phase, 2 = 256x256 phased, 3 = 256x256 ring
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])    # 1 = 128x128, 2 = 256x256 four-phase, 3 = ring, 4 = persistent
 def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(0)
@@ -37,7 +37,7 @@ def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     assert np.array_equal(debug_gemm(a, w, kernel=kernel), a @ w.T)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
 def test_gemm_mfma_random(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(1)

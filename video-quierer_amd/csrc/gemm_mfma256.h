@@ -451,16 +451,4 @@ static int launch_gemm_tn256_stamped(hipStream_t st, const uint16_t* A, int lda,
     return 0;
 }
 
-// Dispatch: the phased 256x256 kernel when the problem tiles by it and yields enough
-// workgroups to occupy the chip, else the 128x128 kernel.
-template <bool IS_F16, class Epi>
-static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
-                            int M, int N, int K, const Epi& epi, int force = 0) {
-    const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
-    const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
-    if (fits256 && want256 && force == 3) return launch_gemm_tn256_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
-    if (fits256 && want256 && force != 1) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
-    return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
-}
-
 }  // namespace vq

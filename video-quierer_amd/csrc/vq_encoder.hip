@@ -6,6 +6,7 @@
 #include "vq_common.h"
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
+#include "gemm_mfma256p.h"
 #include "encoder_kernels.h"
 
 #include <cmath>
