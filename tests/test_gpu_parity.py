@@ -384,3 +384,73 @@ def test_simple_video_index_matches_reference_semantics(gpu_lib, tmp_path):
     assert [g["frame_id"] for g in fresh.search(emb[123], 5)] == [g["frame_id"] for g in idx.search(emb[123], 5)]
     idx.add_frame(emb[123] * 3, "late.mp4", 1.0)                         # incremental add after a search
     assert idx.search(emb[123], 1)[0]["frame_id"] == 300
+
+
+# ------------------------------------------------------------------ threading / wrappers / odd sizes
+def test_handles_are_thread_safe(gpu_lib, b32_weights):
+    """extract_batch runs from asyncio executor threads and search from a 4-thread pool in the reference
+    (feature_extractor.py:215-216, hnsw.py:291-294): concurrent calls on ONE handle must equal serial calls."""
+    from concurrent.futures import ThreadPoolExecutor
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=16)
+    frames = synth_frames(48, seed=5)
+    serial = [fx.extract_batch(list(frames[i:i + 8])) for i in range(0, 48, 8)]
+    with ThreadPoolExecutor(4) as pool:
+        par = list(pool.map(lambda i: fx.extract_batch(list(frames[i:i + 8])), range(0, 48, 8)))
+    for a, b in zip(serial, par):
+        assert np.array_equal(a, b)
+    vecs = np.random.default_rng(3).standard_normal((3000, 512)).astype(np.float32)
+    idx = _mk_index(vecs)
+    qs = list(np.concatenate(serial))
+    want = idx.search_batch(qs, 7)
+    with ThreadPoolExecutor(4) as pool:
+        got = list(pool.map(lambda q: idx.search(q, 7), qs))
+    assert [[r["id"] for r in rr] for rr in got] == [[r["id"] for r in rr] for rr in want]
+    fx.thread_pool.shutdown(); idx.thread_pool.shutdown()
+
+
+def test_async_wrappers_over_the_dropin(gpu_lib):
+    import asyncio
+    from video_quierer_amd.core.feature_extractor import BatchProcessor, CachedFeatureExtractor
+    fx = CachedFeatureExtractor(model_name="seed:1234", batch_size=4, device_batch=8, cache_size=2)
+    frames = synth_frames(6, seed=8)
+    direct = fx.extract_batch(list(frames))
+
+    async def run():
+        bp = BatchProcessor(fx, timeout_ms=5)
+        outs = await asyncio.gather(*[bp.process_request(f"r{i}", [frames[i]]) for i in range(6)])
+        batch = await fx.extract_batch_async(list(frames[:3]))
+        return outs, batch
+    outs, batch = asyncio.run(run())
+    for i, o in enumerate(outs):
+        assert o.shape == (512,) and float(np.dot(o, direct[i])) > 1 - 1e-4
+    assert np.allclose(batch, direct[:3], atol=2e-3)
+    a = fx.extract_features(frames[0]); b = fx.extract_features(frames[0])
+    assert np.array_equal(a, b) and fx.get_cache_stats()["cache_hits"] == 1
+    fx.extract_features(frames[1]); fx.extract_features(frames[2])          # evicts (cache_size=2)
+    assert fx.get_cache_stats()["cache_size"] == 2
+
+
+def test_search_large_k_and_tiny_batches(gpu_lib, b32_weights):
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.indexes.hnsw import MODE_FP16
+    from video_quierer_amd.weights import VIT_B_32
+    rng = np.random.default_rng(41)
+    vecs = rng.standard_normal((17000, 512)).astype(np.float32)
+    idx = _mk_index(vecs)                                        # auto mode: > 16384 rows -> fp16 scan when k <= 32
+    qs = rng.standard_normal((5, 512)).astype(np.float32)
+    stored = idx._export()
+    uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    for k in (33, 100):                                          # beyond the scan's candidate pool -> exact scan
+        res = idx.search_batch(list(qs), k)
+        oid, od = knn_oracle.topk(stored, uq, k)
+        assert np.array_equal(np.array([[r["id"] for r in rr] for rr in res]), oid)
+    idx.search_mode = MODE_FP16
+    with pytest.raises(ValueError):
+        idx.search(qs[0], 64)
+    enc = VitEncoder(VIT_B_32, b32_weights, max_batch=1)        # smallest workspace, one frame at a time
+    f = synth_frames(3, seed=2)
+    one_by_one = enc.encode(f)
+    ref = clip_vit_oracle.encode_frames(f, b32_weights, batch_size=1)
+    assert np.sum(one_by_one * ref, axis=1).min() >= 1 - COS_TOL
+    enc.close()
