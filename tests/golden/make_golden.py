@@ -12,6 +12,7 @@ Produces
                              build's seeded weights: L2-normalised [64,512] fp32
                              embeddings, the un-normalised features, and a
                              checksum of the frames/weights they came from.
+  encoder_l14_336_seed1234.npz   (`make_golden.py l14`) 2 frames through the ViT-L/14@336 geometry.
   knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
                              OptimizedHNSWIndex, random.seed(0)) over 1,000
                              seeded vectors: its levels, entry point and graph,
@@ -79,6 +80,37 @@ def capture_encoder():
     return emb.numpy().astype(np.float32)
 
 
+def capture_encoder_l14():
+    """ViT-L/14@336 (BASELINE configs[4]): 2 synthetic 336x336 frames through transformers' CLIP with the
+    build's seeded L/14 weights — pins the 577-token / patch-14 / hidden-1024 path of the restatement."""
+    import torch
+    from transformers import CLIPConfig, CLIPModel
+    from video_quierer_amd.weights import VIT_L_14_336, seeded_weights
+
+    cfg = VIT_L_14_336
+    W = seeded_weights(cfg, WEIGHT_SEED)
+    hf = CLIPConfig(vision_config=dict(hidden_size=cfg.hidden, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers,
+                                       num_attention_heads=cfg.heads, image_size=cfg.image_size, patch_size=cfg.patch_size),
+                    projection_dim=cfg.proj_dim)
+    model = CLIPModel(hf).eval()
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
+    x = torch.from_numpy(np.ascontiguousarray(frames[..., ::-1])).permute(0, 3, 1, 2).float() / 255.0
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    with torch.no_grad():
+        out = model.get_image_features((x - mean) / std)
+        feats = out.pooler_output if hasattr(out, "pooler_output") else out
+        emb = torch.nn.functional.normalize(feats, p=2, dim=1)
+    np.savez_compressed(os.path.join(HERE, "encoder_l14_336_seed1234.npz"), embeddings=emb.numpy().astype(np.float32),
+                        frame_seed=FRAME_SEED, weight_seed=WEIGHT_SEED,
+                        frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
+
+
 def capture_knn(queries):
     sys.path.insert(0, "/root/reference/src")
     from indexes.hnsw import OptimizedHNSWIndex        # the real reference
@@ -109,6 +141,9 @@ def capture_knn(queries):
 
 
 if __name__ == "__main__":
+    if "l14" in sys.argv[1:]:
+        capture_encoder_l14()
+        sys.exit(0)
     emb = capture_encoder()
     capture_knn(emb)
     print("golden vectors written to", HERE)

@@ -454,3 +454,39 @@ def test_search_large_k_and_tiny_batches(gpu_lib, b32_weights):
     ref = clip_vit_oracle.encode_frames(f, b32_weights, batch_size=1)
     assert np.sum(one_by_one * ref, axis=1).min() >= 1 - COS_TOL
     enc.close()
+
+
+# ------------------------------------------------------------------ other geometries (streaming attention, patch 14)
+def test_encoder_small_patch14_geometry_vs_oracle(gpu_lib):
+    """65 tokens (> one attention tile), patch 14 (generic patch extraction, K padded 588 -> 640), 2 blocks."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VitConfig, seeded_weights
+    cfg = VitConfig(image_size=112, patch_size=14, hidden=768, mlp=3072, layers=2, heads=12, proj_dim=512)
+    W = seeded_weights(cfg, 77)
+    frames = np.random.default_rng(9).integers(0, 255, (5, 112, 112, 3), dtype=np.uint8)
+    ref = clip_vit_oracle.encode_frames(frames, W, patch=14, heads=12, layers=2, batch_size=5)
+    for dt, tol in (("bf16", 5e-3), ("fp16", 8e-4)):
+        enc = VitEncoder(cfg, W, max_batch=8, compute_dtype=dt)
+        emb = enc.encode(frames)
+        enc.close()
+        err = np.linalg.norm(emb - ref, axis=1).max()
+        assert err <= tol, (dt, err)
+
+
+def test_encoder_vit_l14_336_matches_golden(gpu_lib):
+    """BASELINE configs[4] model: ViT-L/14@336, fp16 operands as that config names (and bf16)."""
+    from conftest import GOLDEN, FRAME_SEED
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_L_14_336, seeded_weights
+    g = np.load(os.path.join(GOLDEN, "encoder_l14_336_seed1234.npz"))
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
+    W = seeded_weights(VIT_L_14_336, 1234)
+    for dt, tol in (("fp16", 2e-3), ("bf16", 1.5e-2)):
+        enc = VitEncoder(VIT_L_14_336, W, max_batch=2, compute_dtype=dt)
+        emb = enc.encode(frames)
+        enc.close()
+        assert emb.shape == (2, 768)
+        err = np.linalg.norm(emb - g["embeddings"], axis=1).max()
+        cos = np.sum(emb * g["embeddings"], axis=1).min()
+        print(f"ViT-L/14@336 {dt}: max L2 err {err:.2e}, min cos {cos:.7f}")
+        assert err <= tol and cos >= 1 - COS_TOL

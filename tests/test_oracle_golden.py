@@ -101,3 +101,17 @@ def test_exact_oracle_edge_cases():
     assert list(ids[0]) == [0, 7] and d[0, 0] == d[0, 1]
     bf = hnsw_oracle.brute_force(dup, list(range(10)), x[0], 2)
     assert [r["id"] for r in bf] == [0, 7]
+
+
+def test_encoder_oracle_matches_transformers_vit_l14_336():
+    """configs[4] geometry (577 tokens, patch 14, hidden 1024, 24 layers, 16 heads, projection 768)."""
+    import os
+    from conftest import GOLDEN, FRAME_SEED
+    from video_quierer_amd.weights import VIT_L_14_336, seeded_weights
+    g = np.load(os.path.join(GOLDEN, "encoder_l14_336_seed1234.npz"))
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+    cfg = VIT_L_14_336
+    emb = clip_vit_oracle.encode_frames(frames, seeded_weights(cfg, 1234), patch=cfg.patch_size, heads=cfg.heads,
+                                        layers=cfg.layers, batch_size=2)
+    assert emb.shape == (2, 768) and np.abs(emb - g["embeddings"]).max() <= 1e-5

@@ -380,6 +380,188 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     }
 }
 
+// ---- streaming attention: any T, head_dim 64, optional causal mask ----
+// One wave per (image, head, 64-query tile); it walks the keys in tiles of 64 with an online softmax
+// (running max m and sum l per query column, O rescaled when the max moves).  Same MFMA formulation as
+// attention_t64_kernel: S^T = K Q^T with the query on the lane axis, P^T reused as the next MFMA's B
+// operand, V^T fragments by ds_read_b64_tr_b16 from a per-wave row-major V tile in LDS.  No workgroup
+// barrier: every LDS byte a wave reads was written by that wave (LDS executes a wave's accesses in order).
+// Used for ViT-L/14@336 (577 tokens) and, with CAUSAL, for the CLIP text tower (77 tokens).
+template <bool F16, bool CAUSAL>
+__global__ __launch_bounds__(256)
+void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                             int tokens, int hidden, int heads, int q_tiles, int total_units) {
+    __shared__ __attribute__((aligned(16))) uint16_t vlds[4][64 * 64];
+    typedef mfma_op<F16> op;
+    typedef typename op::frag frag;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * 4 + wave;                 // ((img * heads) + head) * q_tiles + qt
+    if (unit >= total_units) return;                        // wave-uniform; no workgroup barriers below
+    const int qt = unit % q_tiles;
+    const int ih = unit / q_tiles;
+    const int head = ih % heads, img = ih / heads;
+    const int ld = 3 * hidden;
+    const uint16_t* base = qkv + (size_t)img * tokens * ld + head * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = qt * 64;
+    uint16_t* vt = vlds[wave];
+
+    frag qf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = q0 + t * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 qv = {0u, 0u, 0u, 0u};
+            if (row < tokens) qv = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
+            qf[t][ks] = __builtin_bit_cast(frag, qv);
+        }
+    }
+    f32x4 o[4][4];                                          // O^T[dt][nt]: d = 16 dt + 4 g + r, query 16 nt + r16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float NEGBIG = -3.0e38f;
+    float m_run[4] = {NEGBIG, NEGBIG, NEGBIG, NEGBIG}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int k_tiles = CAUSAL ? qt + 1 : (tokens + 63) / 64;
+    const int q4 = r16 >> 2, p4 = r16 & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        const int k0 = kt * 64;
+        // V tile -> LDS (rows beyond the sequence zero-filled)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int id = it * 64 + lane, row = id >> 3, c = id & 7;
+            uint4 val = {0u, 0u, 0u, 0u};
+            if (k0 + row < tokens) val = *(const uint4*)(base + 2 * hidden + (size_t)(k0 + row) * ld + c * 8);
+            *(uint4*)(vt + row * 64 + c * 8) = val;
+        }
+        frag kf[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = k0 + t * 16 + r16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 kv = {0u, 0u, 0u, 0u};
+                if (row < tokens) kv = *(const uint4*)(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
+                kf[t][ks] = __builtin_bit_cast(frag, kv);
+            }
+        }
+        f32x4 sc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = op::run(kf[mt][0], qf[nt][0], a);
+                a = op::run(kf[mt][1], qf[nt][1], a);
+                sc[mt][nt] = a;
+            }
+        float alpha[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int query = q0 + nt * 16 + r16;
+            float mx = NEGBIG;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + mt * 16 + g * 4 + r;
+                    if (key >= tokens || (CAUSAL && key > query)) sc[mt][nt][r] = NEGBIG;
+                    mx = fmaxf(mx, sc[mt][nt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[nt], mx);
+            alpha[nt] = __expf(m_run[nt] - m_new);          // 0 on the first tile (m_run = -3e38)
+            float sum = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // a masked score equals NEGBIG exactly; exp(NEGBIG - m_new) must be 0 even when m_new is NEGBIG too
+                    const float p = sc[mt][nt][r] <= NEGBIG ? 0.f : __expf(sc[mt][nt][r] - m_new);
+                    sc[mt][nt][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            l_run[nt] = l_run[nt] * alpha[nt] + sum;
+            m_run[nt] = m_new;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                o[dt][nt][0] *= alpha[nt]; o[dt][nt][1] *= alpha[nt]; o[dt][nt][2] *= alpha[nt]; o[dt][nt][3] *= alpha[nt];
+            }
+        frag pf[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const uint2 plo = pack4_h<F16>(sc[2 * ss][nt]), phi = pack4_h<F16>(sc[2 * ss + 1][nt]);
+                pf[nt][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
+            }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int key0 = 32 * ss + 4 * g + q4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + key0 * 64 + dt * 16 + p4 * 4));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + (key0 + 16) * 64 + dt * 16 + p4 * 4));
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const frag vf = __builtin_bit_cast(frag, both);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) o[dt][nt] = op::run(vf, pf[nt][ss], o[dt][nt]);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int qrow = q0 + nt * 16 + r16;
+        const float inv = 1.0f / l_run[nt];
+        if (qrow < tokens) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 v = o[dt][nt];
+                v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                *(uint2*)(out + ((size_t)img * tokens + qrow) * hidden + head * 64 + dt * 16 + g * 4) = pack4_h<F16>(v);
+            }
+        }
+    }
+}
+
+// Generic patch extraction (any patch size, e.g. 14): one thread per (image, patch, channel, ky) writes
+// the ps values of that patch row and, for ky == 0 of channel 0, zero-fills the K padding of the row.
+template <bool F16>
+__global__ __launch_bounds__(256)
+void patchify_generic_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ out,
+                             int n, int S, int ps, int k_pad, int swap_rb) {
+    const int grid = S / ps;
+    const int64_t total = (int64_t)n * grid * grid * 3 * ps;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int ky = (int)(t % ps);
+        int64_t u = t / ps;
+        const int c = (int)(u % 3); u /= 3;
+        const int gx = (int)(u % grid); u /= grid;
+        const int gy = (int)(u % grid);
+        const int b = (int)(u / grid);
+        const int cs = swap_rb ? 2 - c : c;
+        const uint8_t* src = frames + (((int64_t)b * S + gy * ps + ky) * S + gx * ps) * 3 + cs;
+        uint16_t* dst = out + ((size_t)(b * grid + gy) * grid + gx) * k_pad + (c * ps + ky) * ps;
+        for (int kx = 0; kx < ps; ++kx) dst[kx] = to_h16<F16>((float)((int)src[kx * 3] - 128));
+        if (c == 0 && ky == 0) {
+            uint16_t* pad = out + ((size_t)(b * grid + gy) * grid + gx) * k_pad + 3 * ps * ps;
+            for (int i = 0; i < k_pad - 3 * ps * ps; ++i) pad[i] = 0;
+        }
+    }
+}
+
 // ============================ pooling head ===================================
 // CLS token -> post_layernorm -> visual_projection (fp32 weights, no bias) ->
 // L2 normalise (x / max(||x||, 1e-12), F.normalize)                 (E8-E10)

@@ -135,12 +135,19 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
 
-    {   // E1/E2 + im2col: uint8 frames -> bf16 patch rows (aliases the MLP buffer)
+    {   // E1/E2 + im2col: uint8 frames -> 16-bit patch rows (aliases the MLP buffer)
         Prof p(e, C_PATCHIFY);
-        const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
-        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(patchify_u8_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
-                           c.image_size, c.patch_size, swap_rb);
+        if (c.patch_size % 8 == 0 && e->patch_k == 3 * c.patch_size * c.patch_size) {
+            const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
+            const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(patchify_u8_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+                               c.image_size, c.patch_size, swap_rb);
+        } else {
+            const int64_t total = (int64_t)n * e->patches * 3 * c.patch_size;
+            const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(patchify_generic_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+                               c.image_size, c.patch_size, e->patch_k, swap_rb);
+        }
     }
     {   // E3: patch-embedding conv as a GEMM, epilogue scatters into token rows + position embedding
         Prof p(e, C_GEMM_PATCH);
@@ -168,8 +175,14 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {
             Prof p(e, C_ATTENTION);
-            hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
-                               c.heads);
+            if (T <= 64 && c.heads % 4 == 0) {
+                hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
+                                   c.heads);
+            } else {
+                const int q_tiles = cdiv(T, 64), units = n * c.heads * q_tiles;
+                hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
+                                   e->att, T, H, c.heads, q_tiles, units);
+            }
         }
         // Only the CLS token of the last block is consumed (E8): its out_proj / LN2 / MLP run on the
         // n CLS rows instead of n*T rows (292.8 MMAC of 4408.8 per frame).  K/V and the
@@ -260,19 +273,16 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     VQ_CHECK(c.layers > 0 && n_weights == 5 + 16 * c.layers + 3, "vq_encoder_create: expected %d weight tensors, got %d",
              5 + 16 * c.layers + 3, n_weights);
     VQ_CHECK(max_batch > 0 && max_batch <= 8192, "vq_encoder_create: max_batch %d out of range", max_batch);
-    VQ_CHECK(c.image_size % c.patch_size == 0 && c.image_size % 8 == 0 && c.patch_size % 8 == 0,
-             "vq_encoder_create: image %d / patch %d: this build needs patch_size %% 8 == 0", c.image_size, c.patch_size);
+    VQ_CHECK(c.image_size > 0 && c.patch_size > 0 && c.image_size % c.patch_size == 0,
+             "vq_encoder_create: image %d is not a multiple of patch %d", c.image_size, c.patch_size);
     const int grid = c.image_size / c.patch_size, patches = grid * grid, tokens = patches + 1;
-    VQ_CHECK(tokens <= 64, "vq_encoder_create: %d tokens; the single-tile attention kernel covers <= 64 "
-             "(ViT-L/14@336 needs the streaming attention kernel, not built yet)", tokens);
+    VQ_CHECK(tokens <= 4096, "vq_encoder_create: %d tokens is beyond what this build sizes for", tokens);
     VQ_CHECK(c.hidden % c.heads == 0 && c.hidden / c.heads == 64, "vq_encoder_create: head_dim must be 64");
-    VQ_CHECK(c.heads % 4 == 0, "vq_encoder_create: heads must be a multiple of 4");
     VQ_CHECK((c.hidden == 768 || c.hidden == 1024) && c.mlp % 128 == 0, "vq_encoder_create: hidden %d / mlp %d unsupported",
              c.hidden, c.mlp);
     VQ_CHECK(c.proj_dim > 0 && c.proj_dim <= 4096, "vq_encoder_create: proj_dim %d out of range", c.proj_dim);
     const int patch_k_raw = 3 * c.patch_size * c.patch_size;
-    const int patch_k = (int)round_up(patch_k_raw, GEMM_BK);
-    VQ_CHECK(patch_k == patch_k_raw, "vq_encoder_create: patch K %d must be a multiple of 64", patch_k_raw);
+    const int patch_k = (int)round_up(patch_k_raw, 2 * G2_BK);     // zero-padded K (ViT-L/14: 588 -> 640)
 
     vq_encoder* e = new vq_encoder();
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
