@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (~15 s of host work)")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="GEMM operand type (BASELINE config: bf16)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default=None,
+                    help="GEMM operand type (default: bf16 for ViT-B/32 as configs[1] names, fp16 for ViT-L/14@336 as configs[4] names)")
+    ap.add_argument("--model", choices=["b32", "l14"], default="b32",
+                    help="b32 = CLIP ViT-B/32 @224 (the headline config); l14 = ViT-L/14 @336 (configs[4] model; use --batch 32)")
+    ap.add_argument("--search-dim", type=int, default=512)
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per step per GPU (BASELINE config: 256)")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: consecutive steps alternate between this many encoder "
@@ -63,6 +67,8 @@ def main():
     global BATCH
     args = parse()
     BATCH = args.batch
+    if args.dtype is None:
+        args.dtype = "fp16" if args.model == "l14" else "bf16"
     import torch
     import torch.distributed as dist
 
@@ -79,10 +85,11 @@ def main():
     from video_quierer_amd import _lib
     from video_quierer_amd.encoder import VitEncoder
     from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
-    from video_quierer_amd.weights import VIT_B_32, seeded_weights
+    from video_quierer_amd.weights import VIT_B_32, VIT_L_14_336, seeded_weights
 
     _lib.init(local)
-    cfg = VIT_B_32
+    cfg = VIT_L_14_336 if args.model == "l14" else VIT_B_32
+    flop_per_frame = 2 * cfg.macs_per_frame()
     weights = seeded_weights(cfg, 1234)
     # one encoder handle per in-flight batch, each on its own torch-owned HIP stream (torch owns it so the
     # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
@@ -96,7 +103,8 @@ def main():
     # synthetic frames, device resident (the reference's randint(0,255) convention), 4 distinct batches per rank
     gen = torch.Generator(device=dev)
     gen.manual_seed(20250824 + rank)
-    pool = [torch.randint(0, 255, (BATCH, 224, 224, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(4)]
+    pool = [torch.randint(0, 255, (BATCH, cfg.image_size, cfg.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
+            for _ in range(4)]
     embs = [torch.empty((BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) for _ in range(nstreams)]
     gath = [torch.empty((world * BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) if world > 1 else None
             for _ in range(nstreams)]
@@ -134,15 +142,17 @@ def main():
         "metric": METRIC, "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: batch-256 ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
-                               "device-resident input (H2D excluded), seeded random-init weights",
+        "config": {"workload": (f"configs[1]: batch-{BATCH} ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
+                                if args.model == "b32" else
+                                f"configs[4] model: batch-{BATCH} ViT-L/14@336 encode of synthetic 336x336 RGB uint8 frames, ")
+                               + "device-resident input (H2D excluded), seeded random-init weights",
                    "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,
                    "parallelism": f"dp{world} (frame shards; RCCL all-gather of embeddings per step)" if world > 1 else "single GPU"},
-        "encode_mfma_frac_whole_pass": frames_per_s / world * FLOP_PER_FRAME / PEAK_BF16,
+        "encode_mfma_frac_whole_pass": frames_per_s / world * flop_per_frame / PEAK_BF16,
         # the last block's out_proj/LN2/MLP run on the CLS rows only (outputs identical): executed work per frame
-        "flop_per_frame": {"algorithmic": FLOP_PER_FRAME,
-                           "executed": FLOP_PER_FRAME - (0 if os.environ.get("VQ_AMD_FULL_LAST_LAYER") == "1"
-                                                         else 2 * 49 * (768 * 768 + 2 * 768 * 3072))},
+        "flop_per_frame": {"algorithmic": flop_per_frame,
+                           "executed": flop_per_frame - (0 if os.environ.get("VQ_AMD_FULL_LAST_LAYER") == "1"
+                                                         else 2 * cfg.patches * (cfg.hidden * cfg.hidden + 2 * cfg.hidden * cfg.mlp))},
     }
 
     if rank == 0:
@@ -186,17 +196,17 @@ def main():
         n_rows, nq, k = args.search_rows // world, args.search_queries, 10
         g2 = torch.Generator(device=dev)
         g2.manual_seed(7 + rank)
-        idx = OptimizedHNSWIndex(dimension=512, device=local)
+        idx = OptimizedHNSWIndex(dimension=args.search_dim, device=local)
         idx.set_stream(stream.cuda_stream)
         for c0 in range(0, n_rows, 250_000):
             c = min(250_000, n_rows - c0)
-            block = torch.randn((c, 512), dtype=torch.float32, device=dev, generator=g2)
+            block = torch.randn((c, args.search_dim), dtype=torch.float32, device=dev, generator=g2)
             torch.cuda.synchronize(dev)                         # generated on torch's default stream, consumed on `stream`
             idx.add_device(block.data_ptr(), c, range(c0, c0 + c), normalize=True)
             torch.cuda.synchronize(dev)
         g3 = torch.Generator(device=dev)
         g3.manual_seed(99)                                      # same queries on every rank
-        q = torch.randn((nq, 512), dtype=torch.float32, device=dev, generator=g3)
+        q = torch.randn((nq, args.search_dim), dtype=torch.float32, device=dev, generator=g3)
         q = q / q.norm(dim=1, keepdim=True)
         ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
         dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
@@ -223,7 +233,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             s_el = float(t.item())
         qps = s_steps * nq / s_el
-        srch = {"value": qps, "unit": "queries/s", "rows": n_rows * world, "queries": nq, "k": k,
+        srch = {"value": qps, "unit": "queries/s", "rows": n_rows * world, "dim": args.search_dim, "queries": nq, "k": k,
                 "ms_per_batch": 1e3 * s_el / s_steps,
                 "mode": "auto: fp16 MFMA scan with per-stream top-2 + exact fp64-chain re-score and proof; "
                         "unproven queries redone by the exact fp32-master scan",
@@ -244,11 +254,14 @@ def main():
         # that only oversubscribe (a 256-thread run measured 0.44 frames/s)
         ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
         torch.set_num_threads(ncores)
-        sample = np.random.default_rng(20250824).integers(0, 255, (args.cpu_frames, 224, 224, 3), dtype=np.uint8)
-        clip_vit_oracle.encode_frames(sample[:8], weights, batch_size=8)          # warm the thread pool
+        ncpu = args.cpu_frames if args.model == "b32" else max(8, args.cpu_frames // 64)
+        sample = np.random.default_rng(20250824).integers(0, 255, (ncpu, cfg.image_size, cfg.image_size, 3), dtype=np.uint8)
+        okw = dict(patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers)
+        clip_vit_oracle.encode_frames(sample[:8], weights, batch_size=8, **okw)   # warm the thread pool
         t0 = time.perf_counter()
-        clip_vit_oracle.encode_frames(sample, weights, batch_size=32)             # reference default batch_size=32
+        clip_vit_oracle.encode_frames(sample, weights, batch_size=32, **okw)      # reference default batch_size=32
         ct = time.perf_counter() - t0
+        args.cpu_frames = ncpu
         out["cpu_baseline"] = {"value": args.cpu_frames / ct, "unit": "frames/s", "cores": torch.get_num_threads(),
                                "kind": "port",
                                "sample": f"{args.cpu_frames} synthetic frames, batch 32, fp32 torch-CPU oracle "
