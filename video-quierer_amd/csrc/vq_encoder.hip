@@ -61,6 +61,7 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     int run_layers = -1;
     int last_n = 0;
+    bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles
@@ -179,9 +180,15 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                 hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
                                    c.heads);
             } else {
-                const int q_tiles = cdiv(T, 64), units = n * c.heads * q_tiles;
-                hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
-                                   e->att, T, H, c.heads, q_tiles, units);
+                const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
+                if (e->attn_simple) {
+                    const int units = n * c.heads * q_tiles;
+                    hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
+                                       e->att, T, H, c.heads, q_tiles, units);
+                } else {
+                    hipLaunchKernelGGL((attention_stream_wg_kernel<F16, false>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
+                                       e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
+                }
             }
         }
         // Only the CLS token of the last block is consumed (E8): its out_proj / LN2 / MLP run on the
@@ -286,6 +293,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
 
     vq_encoder* e = new vq_encoder();
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* at = getenv("VQ_AMD_ATTN")) e->attn_simple = !strcmp(at, "simple");
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->fp16 = (flags & VQ_ENC_FP16) != 0;
     if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
