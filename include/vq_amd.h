@@ -111,6 +111,30 @@ int vq_encoder_debug_read(vq_encoder* enc, const char* name, int rows, float* ou
  * two-phase, 2 = 256x256 phased). */
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C);
 
+/* ---- text tower: FeatureExtractor.extract_text_features (feature_extractor.py:218-234) ------------ */
+/* CLIPTextModel + text_projection on token ids (the tokenizer stays on the host).  weights: host fp32
+ * tensors in the order of video-quierer_amd/weights.py:text_weight_shapes() (2 + 16*layers + 3).
+ * flags as vq_encoder_create_ex. */
+typedef struct vq_encoder vq_text_encoder;
+typedef struct vq_text_config {
+    int32_t vocab;          /* 49408 */
+    int32_t max_positions;  /* 77 */
+    int32_t hidden;         /* 512 */
+    int32_t mlp;            /* 2048 */
+    int32_t layers;         /* 12 */
+    int32_t heads;          /* 8 */
+    int32_t proj_dim;       /* 512 */
+    int32_t eos_token_id;   /* 49407 */
+    float ln_eps;           /* 1e-5 */
+} vq_text_config;
+int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weights, int n_weights,
+                           int max_batch, int flags, vq_text_encoder** out);
+/* ids [n][seq_len] (seq_len <= max_positions; every row holds an eos token, as the tokenizer produces):
+ * out [n][proj_dim] fp32, L2-normalised.  Rows are padded to max_positions with eos internally (the
+ * causal mask makes the padding invisible to the pooled EOS position).  Synchronous; any n. */
+int vq_text_encoder_encode_ids(vq_text_encoder* enc, const int32_t* ids, int n, int seq_len, float* out);
+int vq_text_encoder_destroy(vq_text_encoder* enc);
+
 /* Diagnostic build of the 256x256 mainloop with in-kernel s_memtime stamps: workgroup 0, 8 waves x
  * 768 stamps (3 per phase: start of read half, after the first barrier, after the MFMAs).
  * diag: bit0 skip the in-loop DMA, bit1 skip the ds_reads, bit2 skip the MFMAs (timing ablations; results invalid). */

@@ -100,6 +100,53 @@ def vit_forward(pixel: torch.Tensor, W: Dict[str, torch.Tensor], *, patch: int, 
     return pooled @ W["visual_projection.weight"].t()
 
 
+def text_forward(input_ids: torch.Tensor, W: Dict[str, torch.Tensor], *, heads: int, layers: int,
+                 eos_token_id: int, eps: float = 1e-5) -> torch.Tensor:
+    """int64 [n,L] token ids -> fp32 [n,proj_dim] (un-normalised text features).
+
+    Restates what ``extract_text_features`` (reference src/core/feature_extractor.py:218-234) gets from
+    ``CLIPModel.get_text_features``: tf:222-256 token + position embeddings, tf:543-554 causal mask,
+    the same pre-LN blocks as the vision tower (tf:362-383), tf:566 final_layer_norm, tf:568-586 pooling at
+    the first EOS position (argmax of the ids for the legacy eos_token_id == 2), text_projection (no bias).
+    """
+    n, L = input_ids.shape
+    p = "text_model."
+    x = W[p + "embeddings.token_embedding.weight"][input_ids] + W[p + "embeddings.position_embedding.weight"][:L]
+    hid = x.shape[-1]
+    dh = hid // heads
+    mask = torch.full((L, L), float("-inf")).triu(1)
+    for l in range(layers):
+        pre = f"{p}encoder.layers.{l}."
+        h = _ln(x, W[pre + "layer_norm1.weight"], W[pre + "layer_norm1.bias"], eps)
+        q = (h @ W[pre + "self_attn.q_proj.weight"].t() + W[pre + "self_attn.q_proj.bias"]).view(n, L, heads, dh).transpose(1, 2)
+        k = (h @ W[pre + "self_attn.k_proj.weight"].t() + W[pre + "self_attn.k_proj.bias"]).view(n, L, heads, dh).transpose(1, 2)
+        v = (h @ W[pre + "self_attn.v_proj.weight"].t() + W[pre + "self_attn.v_proj.bias"]).view(n, L, heads, dh).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5 + mask, dim=-1, dtype=torch.float32)
+        o = (a @ v).transpose(1, 2).reshape(n, L, hid)
+        x = x + (o @ W[pre + "self_attn.out_proj.weight"].t() + W[pre + "self_attn.out_proj.bias"])
+        h = _ln(x, W[pre + "layer_norm2.weight"], W[pre + "layer_norm2.bias"], eps)
+        h = h @ W[pre + "mlp.fc1.weight"].t() + W[pre + "mlp.fc1.bias"]
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + (h @ W[pre + "mlp.fc2.weight"].t() + W[pre + "mlp.fc2.bias"])
+    x = _ln(x, W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], eps)
+    if eos_token_id == 2:
+        pos = input_ids.argmax(dim=-1)
+    else:
+        pos = (input_ids == eos_token_id).int().argmax(dim=-1)
+    pooled = x[torch.arange(n), pos]
+    return pooled @ W["text_projection.weight"].t()
+
+
+def encode_token_ids(input_ids: np.ndarray, weights: Dict[str, np.ndarray], *, heads: int = 8, layers: int = 12,
+                     eos_token_id: int = 49407, eps: float = 1e-5) -> np.ndarray:
+    """int [n,L] -> np.float32 [n,proj_dim], L2-normalised (feature_extractor.py:226-230)."""
+    W = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
+    with torch.no_grad():
+        f = text_forward(torch.from_numpy(np.asarray(input_ids, dtype=np.int64)), W, heads=heads, layers=layers,
+                         eos_token_id=eos_token_id, eps=eps)
+        return l2_normalize(f).numpy().astype(np.float32)
+
+
 def l2_normalize(f: torch.Tensor) -> torch.Tensor:
     """F.normalize(p=2, dim=1): x / max(||x||, 1e-12) (feature_extractor.py:157)."""
     return f / f.norm(dim=1, keepdim=True).clamp_min(1e-12)

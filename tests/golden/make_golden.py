@@ -13,6 +13,7 @@ Produces
                              embeddings, the un-normalised features, and a
                              checksum of the frames/weights they came from.
   encoder_l14_336_seed1234.npz   (`make_golden.py l14`) 2 frames through the ViT-L/14@336 geometry.
+  text_b32_seed1234.npz      (`make_golden.py text`) 16 synthetic prompts (token ids) through the text tower.
   knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
                              OptimizedHNSWIndex, random.seed(0)) over 1,000
                              seeded vectors: its levels, entry point and graph,
@@ -111,6 +112,43 @@ def capture_encoder_l14():
                         frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
 
 
+def synth_token_ids(n=16, seed=4242, max_len=77):
+    """Synthetic prompts: [bos] + random word-piece ids + [eos], padded with eos to the longest (what
+    CLIPProcessor(padding=True) produces for a batch); lengths 3..77."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(3, max_len + 1, n)
+    lens[0], lens[1] = max_len, 3
+    L = int(lens.max())
+    ids = np.full((n, L), 49407, dtype=np.int64)
+    for i, ln in enumerate(lens):
+        ids[i, 0] = 49406
+        ids[i, 1:ln - 1] = rng.integers(0, 49406, ln - 2)
+        ids[i, ln - 1] = 49407
+    return ids
+
+
+def capture_text():
+    """16 synthetic prompts through transformers' CLIP text tower carrying the build's seeded text weights."""
+    import torch
+    from transformers import CLIPConfig, CLIPModel
+    from video_quierer_amd.weights import TEXT_B_32, seeded_text_weights
+
+    W = seeded_text_weights(TEXT_B_32, WEIGHT_SEED)
+    model = CLIPModel(CLIPConfig()).eval()
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    ids = synth_token_ids()
+    with torch.no_grad():
+        out = model.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.ones_like(torch.from_numpy(ids)))
+        feats = out.pooler_output if hasattr(out, "pooler_output") else out
+        emb = torch.nn.functional.normalize(feats, p=2, dim=1)
+    np.savez_compressed(os.path.join(HERE, "text_b32_seed1234.npz"), input_ids=ids.astype(np.int32),
+                        embeddings=emb.numpy().astype(np.float32), weight_seed=WEIGHT_SEED)
+
+
 def capture_knn(queries):
     sys.path.insert(0, "/root/reference/src")
     from indexes.hnsw import OptimizedHNSWIndex        # the real reference
@@ -143,6 +181,9 @@ def capture_knn(queries):
 if __name__ == "__main__":
     if "l14" in sys.argv[1:]:
         capture_encoder_l14()
+        sys.exit(0)
+    if "text" in sys.argv[1:]:
+        capture_text()
         sys.exit(0)
     emb = capture_encoder()
     capture_knn(emb)

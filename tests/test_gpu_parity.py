@@ -158,7 +158,7 @@ def test_feature_extractor_api(gpu_lib, b32_weights):
     assert set(st) == {"total_processed", "avg_extraction_time", "throughput_images_per_sec", "device",
                        "model_name", "output_dimension"} and st["total_processed"] == 72
     with pytest.raises(NotImplementedError):
-        fx.extract_text_features("a cat")
+        fx.extract_text_features("a cat")          # seeded model: no tokenizer files
     with pytest.raises(RuntimeError):
         FeatureExtractor(model_name="seed:1234", device="cpu")
     fx.thread_pool.shutdown()
@@ -490,3 +490,35 @@ def test_encoder_vit_l14_336_matches_golden(gpu_lib):
         cos = np.sum(emb * g["embeddings"], axis=1).min()
         print(f"ViT-L/14@336 {dt}: max L2 err {err:.2e}, min cos {cos:.7f}")
         assert err <= tol and cos >= 1 - COS_TOL
+
+
+# ------------------------------------------------------------------ text tower ("next" #1)
+def test_text_tower_matches_golden(gpu_lib):
+    """16 synthetic prompts (token ids) vs transformers' get_text_features on the same seeded weights."""
+    from video_quierer_amd.text_encoder import TextEncoder
+    from video_quierer_amd.weights import TEXT_B_32, seeded_text_weights
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "text_b32_seed1234.npz"))
+    W = seeded_text_weights(TEXT_B_32, 1234)
+    for dt, tol in (("bf16", 8e-3), ("fp16", 1.2e-3)):
+        enc = TextEncoder(TEXT_B_32, W, max_batch=8, compute_dtype=dt)      # 16 prompts -> two device passes
+        emb = enc.encode_ids(g["input_ids"])
+        short = enc.encode_ids(g["input_ids"][1:2, :3])                      # a 3-token prompt given un-padded
+        enc.close()
+        err = np.linalg.norm(emb - g["embeddings"], axis=1)
+        print(f"text tower {dt}: max L2 err {err.max():.2e}, min cos {np.sum(emb * g['embeddings'], axis=1).min():.7f}")
+        assert err.max() <= tol and np.sum(emb * g["embeddings"], axis=1).min() >= 1 - COS_TOL
+        assert np.abs(short[0] - emb[1]).max() <= 1e-6                        # padding is invisible to the EOS position
+    ref = clip_vit_oracle.encode_token_ids(g["input_ids"], W)
+    assert np.abs(ref - g["embeddings"]).max() <= 1e-5
+
+
+def test_feature_extractor_text_ids(gpu_lib):
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=8)
+    ids = np.array([49406, 320, 1125, 539, 320, 2368, 49407])               # "a photo of a cat"-shaped prompt
+    v = fx.extract_text_features_from_ids(ids)
+    assert v.shape == (512,) and v.dtype == np.float32 and abs(np.linalg.norm(v) - 1) < 1e-5
+    both = fx.extract_text_features_from_ids(np.stack([ids, ids[::-1].copy()]))
+    assert both.shape == (2, 512) and np.allclose(both[0], v, atol=1e-6)
+    fx.thread_pool.shutdown()

@@ -115,3 +115,16 @@ def test_encoder_oracle_matches_transformers_vit_l14_336():
     emb = clip_vit_oracle.encode_frames(frames, seeded_weights(cfg, 1234), patch=cfg.patch_size, heads=cfg.heads,
                                         layers=cfg.layers, batch_size=2)
     assert emb.shape == (2, 768) and np.abs(emb - g["embeddings"]).max() <= 1e-5
+
+
+def test_text_oracle_matches_transformers():
+    import os
+    from conftest import GOLDEN
+    from video_quierer_amd.weights import TEXT_B_32, seeded_text_weights
+    g = np.load(os.path.join(GOLDEN, "text_b32_seed1234.npz"))
+    W = seeded_text_weights(TEXT_B_32, 1234)
+    emb = clip_vit_oracle.encode_token_ids(g["input_ids"], W)
+    assert np.abs(emb - g["embeddings"]).max() <= 1e-5
+    pad = np.full((g["input_ids"].shape[0], 77), 49407, dtype=np.int64)
+    pad[:, :g["input_ids"].shape[1]] = g["input_ids"]
+    assert np.array_equal(clip_vit_oracle.encode_token_ids(pad, W), emb)     # eos padding never reaches the pooled row

@@ -25,6 +25,12 @@ class VqError(RuntimeError):
     """A libvq_amd call failed (message from vq_last_error)."""
 
 
+class TextConfigC(ctypes.Structure):
+    _fields_ = [("vocab", c_int32), ("max_positions", c_int32), ("hidden", c_int32), ("mlp", c_int32),
+                ("layers", c_int32), ("heads", c_int32), ("proj_dim", c_int32), ("eos_token_id", c_int32),
+                ("ln_eps", c_float)]
+
+
 class VitConfigC(ctypes.Structure):
     _fields_ = [("image_size", c_int32), ("patch_size", c_int32), ("hidden", c_int32), ("mlp", c_int32),
                 ("layers", c_int32), ("heads", c_int32), ("proj_dim", c_int32), ("ln_eps", c_float)]
@@ -49,6 +55,9 @@ SIGNATURES = {
     "vq_encoder_profile_class_name": (c_char_p, [c_int]),
     "vq_encoder_debug_set_layers": (c_int, [c_void_p, c_int]),
     "vq_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_float)]),
+    "vq_text_encoder_create": (c_int, [POINTER(TextConfigC), POINTER(POINTER(c_float)), c_int, c_int, c_int, POINTER(c_void_p)]),
+    "vq_text_encoder_encode_ids": (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, POINTER(c_float)]),
+    "vq_text_encoder_destroy": (c_int, [c_void_p]),
     "vq_debug_gemm": (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_debug_gemm_stamps": (c_int, [c_int, c_int, c_int, c_int, POINTER(ctypes.c_uint64)]),
     "vq_debug_gemm_ablate": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]),

@@ -8,8 +8,9 @@ What differs from the reference, deliberately:
 * ``model_name`` is never fetched from the hub.  It is a local HF checkpoint
   directory, a known name resolved under ``$VQ_AMD_MODEL_DIR``, or
   ``"seed:<int>"`` for deterministic synthetic weights (weights.py).
-* ``extract_text_features`` needs the CLIP text tower + tokenizer files, which
-  are "next" in SURVEY.md §8f; it raises NotImplementedError.
+* ``extract_text_features`` runs the CLIP text tower on the GPU; tokenisation needs the
+  checkpoint's vocab.json / merges.txt (never fetched).  Seeded models have no tokenizer:
+  use ``extract_text_features_from_ids``.
 * GEMMs run in bf16 with fp32 accumulation; embeddings agree with the fp32
   reference to cosine >= 1 - 1e-3 (tests/test_gpu_parity.py); ``compute_dtype="fp16"``
   switches the operands to fp16 (8x smaller error, same speed).
@@ -68,7 +69,8 @@ class FeatureExtractor:
             raise RuntimeError("FeatureExtractor(device='cpu'): this build has no CPU path (MI355X only)")
         ordinal = int(dev.split(":")[1]) if ":" in dev else None
         self.model = None
-        self.processor = None        # reference: CLIPProcessor (text tokenizer); see extract_text_features
+        self.processor = None        # reference: CLIPProcessor; here the CLIP tokenizer, loaded with the text tower
+        self._text = None
         self._ordinal = ordinal
         self._load_model()
         self.device = _DeviceName(f"cuda:{self.model.device}")
@@ -188,11 +190,38 @@ class FeatureExtractor:
         loop = asyncio.get_event_loop()                               # reference :211-216
         return await loop.run_in_executor(None, self.extract_batch, images)
 
+    # -- text tower -----------------------------------------------------------
+    def _text_model(self):
+        """The text tower is built on first use (the reference loads both towers up front, :76-77)."""
+        if self._text is None:
+            from video_quierer_amd.text_encoder import TextEncoder, load_tokenizer
+            from video_quierer_amd.weights import resolve_text_model
+            tcfg, tweights, tok_dir = resolve_text_model(self.model_name)
+            self._text = TextEncoder(tcfg, tweights, max_batch=64, device=self._ordinal, compute_dtype=self.compute_dtype)
+            self.processor = load_tokenizer(tok_dir)       # reference attr: CLIPProcessor
+        return self._text
+
+    def extract_text_features_from_ids(self, input_ids) -> np.ndarray:
+        """Token ids ``[L]`` or ``[n, L]`` (bos … eos) → L2-normalised fp32 ``[proj_dim]`` / ``[n, proj_dim]``."""
+        ids = np.asarray(input_ids)
+        out = self._text_model().encode_ids(ids)
+        return out[0] if ids.ndim == 1 else out
+
     def extract_text_features(self, text: str) -> np.ndarray:
-        """Reference :218-234.  The text tower and its tokenizer files (vocab.json /
-        merges.txt, hub-only) are outside this round's scope (SURVEY.md §8f #1)."""
-        logger.error("Text feature extraction failed: text tower not built")
-        raise NotImplementedError("CLIP text encoder is not part of this build yet; pass a query vector instead")
+        """Reference :218-234: tokenise → text tower → L2 normalise → fp32 ``[proj_dim]``.
+        Needs the checkpoint's tokenizer files (vocab.json / merges.txt); with seeded weights there are
+        none, so only ``extract_text_features_from_ids`` works."""
+        try:
+            model = self._text_model()
+            if self.processor is None:
+                raise NotImplementedError(
+                    "no tokenizer files next to the checkpoint (seeded models have none): "
+                    "use extract_text_features_from_ids(ids) or pass a query vector")
+            ids = self.processor([text], padding=True, truncation=True, max_length=model.cfg.max_positions)["input_ids"]
+            return model.encode_ids(np.asarray(ids))[0]
+        except Exception as e:
+            logger.error(f"Text feature extraction failed: {e}")
+            raise
 
     def get_stats(self) -> Dict[str, Any]:
         """Reference :236-258 (same keys, including the full-batch assumption of the throughput figure)."""

@@ -236,6 +236,50 @@ void gather_rows_h16_kernel(const uint16_t* __restrict__ src, uint16_t* __restri
     }
 }
 
+// ---- text tower embedding (tf:222-256): x = token_embedding[id] + position_embedding[t]; h = LN1(x) ----
+template <int NV, bool F16>
+__global__ __launch_bounds__(256)
+void embed_tokens_kernel(const int* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                         float* __restrict__ x, uint16_t* __restrict__ h,
+                         const float* __restrict__ g_ln1, const float* __restrict__ b_ln1,
+                         int rows, int seq, int vocab, float eps) {
+    constexpr int H = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int t = row % seq;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int o = (i * 64 + lane) * 4;
+        const float4 a = *(const float4*)(tok + (size_t)id * H + o), p = *(const float4*)(pos + (size_t)t * H + o);
+        v[i] = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
+        *(float4*)(x + (size_t)row * H + o) = v[i];
+    }
+    ln_row<NV>(v, g_ln1, b_ln1, lane, eps, H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+}
+
+// pooling row of every sequence (tf:568-586): first position holding eos_token_id (position 0 if none);
+// for the legacy eos_token_id == 2 checkpoints, the position of the largest id.
+__global__ void eos_rows_kernel(const int* __restrict__ ids, int* __restrict__ row_index, int n, int seq, int eos_id) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int* p = ids + (size_t)s * seq;
+    int pos = 0;
+    if (eos_id == 2) {
+        int best = p[0];
+        for (int t = 1; t < seq; ++t) if (p[t] > best) { best = p[t]; pos = t; }
+    } else {
+        for (int t = 0; t < seq; ++t) if (p[t] == eos_id) { pos = t; break; }
+    }
+    row_index[s] = s * seq + pos;
+}
+
 // ============================ attention ======================================
 // Single-tile softmax attention for T <= 64 tokens, head_dim = 64 (E6).
 // One wave per (image, head); a 256-thread workgroup covers 4 heads of one image.
@@ -762,7 +806,8 @@ __global__ __launch_bounds__(256)
 void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ g,
                          const float* __restrict__ b, const float* __restrict__ wproj_t,
                          float* __restrict__ feat /*[n][proj_dim], un-normalised*/,
-                         int n_images, int tokens, int proj_dim, float eps) {
+                         int n_images, int tokens, int proj_dim, float eps,
+                         const int* __restrict__ row_index = nullptr /*text tower: EOS row of every sequence*/) {
     constexpr int H = NV * 256;
     __shared__ __attribute__((aligned(16))) float xn[POOL_IMGS][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -773,8 +818,9 @@ void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ 
         const int im = wave * 2 + j;
         const int img = min(img0 + im, n_images - 1);            // tail group: duplicate the last image
         float4 v[NV];
+        const size_t row = row_index ? (size_t)row_index[img] : (size_t)img * tokens;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)img * tokens * H + (i * 64 + lane) * 4);
+        for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + row * H + (i * 64 + lane) * 4);
         ln_row<NV>(v, g, b, lane, eps, H);
 #pragma unroll
         for (int i = 0; i < NV; ++i) *(float4*)(&xn[im][(i * 64 + lane) * 4]) = v[i];

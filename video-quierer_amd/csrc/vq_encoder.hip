@@ -61,6 +61,8 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     int run_layers = -1;
     int last_n = 0;
+    bool is_text = false;       // CLIP text tower (vq_text_encoder_*): token embedding, causal attention, EOS pooling
+    float* tok_emb = nullptr; int* d_ids = nullptr; int* d_rowidx = nullptr; int vocab = 0, eos_id = 0;
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
@@ -121,7 +123,8 @@ int upload_h16(uint16_t* dst, const float* src, size_t n, bool f16, float scale 
 }
 
 template <int NV, bool F16>
-int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
+int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16,
+                const int* d_ids = nullptr) {
     const vq_vit_config& c = e->cfg;
     hipStream_t st = e->stream;
     const int H = c.hidden, T = e->tokens;
@@ -136,6 +139,14 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
 
+    const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
+    if (e->is_text) {
+        Prof p(e, C_EMBED_FINISH);
+        const LayerW& L0 = e->layers[0];
+        hipLaunchKernelGGL((embed_tokens_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, d_ids, e->tok_emb, e->pos,
+                           e->x, e->h, L0.ln1_g, L0.ln1_b, rows, T, e->vocab, c.ln_eps);
+        hipLaunchKernelGGL(eos_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_ids, e->d_rowidx, n, T, e->eos_id);
+    } else {
     {   // E1/E2 + im2col: uint8 frames -> 16-bit patch rows (aliases the MLP buffer)
         Prof p(e, C_PATCHIFY);
         if (c.patch_size % 8 == 0 && e->patch_k == 3 * c.patch_size * c.patch_size) {
@@ -155,12 +166,12 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
                                         EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force)));
     }
-    const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
     {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
         Prof p(e, C_EMBED_FINISH);
         const LayerW& L0 = e->layers[0];
         hipLaunchKernelGGL((embed_finish_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
                            e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
+    }
     }
     for (int l = 0; l < nl; ++l) {
         const LayerW& L = e->layers[l];
@@ -176,7 +187,11 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {
             Prof p(e, C_ATTENTION);
-            if (T <= 64 && c.heads % 4 == 0) {
+            if (e->is_text) {
+                const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
+                hipLaunchKernelGGL((attention_stream_wg_kernel<F16, true>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
+                                   e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
+            } else if (T <= 64 && c.heads % 4 == 0) {
                 hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
                                    c.heads);
             } else {
@@ -194,7 +209,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         // Only the CLS token of the last block is consumed (E8): its out_proj / LN2 / MLP run on the
         // n CLS rows instead of n*T rows (292.8 MMAC of 4408.8 per frame).  K/V and the
         // attention itself still cover every token.  $VQ_AMD_FULL_LAST_LAYER=1 disables the pruning.
-        const bool cls_only = e->prune_last && e->run_layers < 0 && l == c.layers - 1;   // debug runs keep every row
+        const bool cls_only = !e->is_text && e->prune_last && e->run_layers < 0 && l == c.layers - 1;   // debug runs keep every row
         if (cls_only) {
             const int crows = pad_rows(n);
             {
@@ -244,7 +259,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     {   // E8-E10
         Prof p(e, C_POOL);
         hipLaunchKernelGGL((pool_project_kernel<NV>), dim3(cdiv(n, POOL_IMGS), cdiv(c.proj_dim, POOL_CHUNK)), dim3(256), 0, st,
-                           e->x, e->post_g, e->post_b, e->w_proj, d_out_f32, n, T, c.proj_dim, c.ln_eps);
+                           e->x, e->post_g, e->post_b, e->w_proj, d_out_f32, n, T, c.proj_dim, c.ln_eps,
+                           e->is_text ? e->d_rowidx : (const int*)nullptr);
         hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, d_out_f32, d_out_f16, n, c.proj_dim);
     }
     VQ_HIP(hipGetLastError());
@@ -252,13 +268,16 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     return 0;
 }
 
-int forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16) {
+int forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16,
+            const int* d_ids = nullptr) {
     const int key = (e->cfg.hidden / 256) * 2 + (e->fp16 ? 1 : 0);
     switch (key) {
-        case 6: return run_forward<3, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
-        case 7: return run_forward<3, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
-        case 8: return run_forward<4, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
-        case 9: return run_forward<4, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16);
+        case 4: return run_forward<2, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 5: return run_forward<2, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 6: return run_forward<3, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 7: return run_forward<3, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 8: return run_forward<4, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 9: return run_forward<4, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
         default: return fail(VQ_ERR_INVALID, "unsupported hidden size %d", e->cfg.hidden);
     }
 }
@@ -394,6 +413,132 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     return 0;
 }
 
+int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weights, int n_weights, int max_batch,
+                           int flags, vq_text_encoder** out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(cfg && weights && out, "vq_text_encoder_create: null argument");
+    const vq_text_config t = *cfg;
+    VQ_CHECK(t.layers > 0 && n_weights == 2 + 16 * t.layers + 3, "vq_text_encoder_create: expected %d weight tensors, got %d",
+             2 + 16 * t.layers + 3, n_weights);
+    VQ_CHECK(max_batch > 0 && max_batch <= 8192, "vq_text_encoder_create: max_batch %d out of range", max_batch);
+    VQ_CHECK(t.hidden % t.heads == 0 && t.hidden / t.heads == 64, "vq_text_encoder_create: head_dim must be 64");
+    VQ_CHECK((t.hidden == 512 || t.hidden == 768 || t.hidden == 1024) && t.mlp % 256 == 0,
+             "vq_text_encoder_create: hidden %d / mlp %d unsupported", t.hidden, t.mlp);
+    VQ_CHECK(t.max_positions > 0 && t.max_positions <= 4096 && t.vocab > 0, "vq_text_encoder_create: bad vocabulary/positions");
+    VQ_CHECK(t.proj_dim > 0 && t.proj_dim <= 4096, "vq_text_encoder_create: proj_dim %d out of range", t.proj_dim);
+
+    vq_encoder* e = new vq_encoder();
+    e->is_text = true;
+    e->cfg = vq_vit_config{0, 0, t.hidden, t.mlp, t.layers, t.heads, t.proj_dim, t.ln_eps};
+    e->tokens = t.max_positions; e->patches = 0; e->grid = 0; e->patch_k = 0; e->max_batch = max_batch;
+    e->vocab = t.vocab; e->eos_id = t.eos_token_id;
+    e->rows_pad = round_up((int64_t)max_batch * e->tokens, 256);
+    e->prow_pad = 0;
+    if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    e->fp16 = (flags & VQ_ENC_FP16) != 0;
+    if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
+    auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
+
+    const size_t H = t.hidden, M = t.mlp, T = e->tokens;
+    size_t bytes = 0;
+    auto add = [&](size_t b) { bytes = ((bytes + 255) & ~(size_t)255) + b; };
+    add((size_t)t.vocab * H * 4); add(T * H * 4); add(H * 4); add(H * 4); add((size_t)t.proj_dim * H * 4);
+    for (int l = 0; l < t.layers; ++l) {
+        for (int i = 0; i < 4; ++i) add(H * 4);
+        add(3 * H * 4); add(H * 4); add(M * 4); add(H * 4);
+        add(3 * H * H * 2); add(H * H * 2); add(M * H * 2); add(H * M * 2);
+    }
+    add((size_t)max_batch * T * 4); add((size_t)max_batch * 4);
+    add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * t.proj_dim * 4);
+    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
+    add((size_t)e->rows_pad * M * 2);
+    bytes += 4096;
+    hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
+    if (he != hipSuccess) { delete e; return fail(VQ_ERR_OOM, "vq_text_encoder_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
+    e->arena.size = bytes;
+    he = hipMemset(e->arena.base, 0, bytes);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
+    he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he)));
+    e->stream = e->own_stream;
+
+    Arena& A = e->arena;
+    int wi = 0, rc = 0;
+#define UP(expr) do { rc = (expr); if (rc) return cleanup(rc); } while (0)
+    e->tok_emb = A.take<float>((size_t)t.vocab * H);   UP(upload_f32(e->tok_emb, weights[wi++], (size_t)t.vocab * H));
+    e->pos = A.take<float>(T * H);                      UP(upload_f32(e->pos, weights[wi++], T * H));
+    e->layers.resize(t.layers);
+    const float qscale = 1.0f / std::sqrt((float)(t.hidden / t.heads));
+    for (int l = 0; l < t.layers; ++l) {
+        LayerW& L = e->layers[l];
+        L.ln1_g = A.take<float>(H);           UP(upload_f32(L.ln1_g, weights[wi++], H));
+        L.ln1_b = A.take<float>(H);           UP(upload_f32(L.ln1_b, weights[wi++], H));
+        L.w_qkv = A.take<uint16_t>(3 * H * H);
+        L.b_qkv = A.take<float>(3 * H);
+        for (int part = 0; part < 3; ++part) {
+            const float sc = part == 0 ? qscale : 1.0f;
+            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->fp16, sc));
+            std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
+            for (auto& v : b) v *= sc;
+            UP(upload_f32(L.b_qkv + part * H, b.data(), H));
+        }
+        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->fp16));
+        L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
+        L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
+        L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
+        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->fp16));
+        L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
+        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->fp16));
+        L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
+    }
+    e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));     // final_layer_norm
+    e->post_b = A.take<float>(H);             UP(upload_f32(e->post_b, weights[wi++], H));
+    e->w_proj = A.take<float>((size_t)t.proj_dim * H);
+    {
+        const float* wp = weights[wi++];
+        std::vector<float> wt((size_t)t.proj_dim * H);
+        for (int o = 0; o < t.proj_dim; ++o)
+            for (size_t k = 0; k < H; ++k) wt[k * t.proj_dim + o] = wp[(size_t)o * H + k];
+        UP(upload_f32(e->w_proj, wt.data(), wt.size()));
+    }
+#undef UP
+    e->d_ids = A.take<int>((size_t)max_batch * T);
+    e->d_rowidx = A.take<int>(max_batch);
+    e->x = A.take<float>((size_t)e->rows_pad * H);
+    e->d_out = A.take<float>((size_t)max_batch * t.proj_dim);
+    e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
+    e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->mlp = A.take<uint16_t>((size_t)e->rows_pad * M);
+    if (A.used > A.size) return cleanup(fail(VQ_ERR_STATE, "arena overflow (%zu > %zu)", A.used, A.size));
+    *out = e;
+    return 0;
+}
+
+int vq_text_encoder_encode_ids(vq_text_encoder* e, const int32_t* ids, int n, int seq_len, float* out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && e->is_text, "vq_text_encoder_encode_ids: not a text encoder handle");
+    VQ_CHECK(n >= 0 && (n == 0 || (ids && out)), "vq_text_encoder_encode_ids: bad argument");
+    VQ_CHECK(seq_len > 0 && seq_len <= e->tokens, "vq_text_encoder_encode_ids: seq_len %d outside (0, %d]", seq_len, e->tokens);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int T = e->tokens;
+    std::vector<int32_t> padded;
+    for (int done = 0; done < n; done += e->max_batch) {
+        const int cur = std::min(e->max_batch, n - done);
+        padded.assign((size_t)cur * T, e->eos_id);                       // pad with eos: invisible to the EOS position (causal)
+        for (int i = 0; i < cur; ++i)
+            std::copy(ids + (size_t)(done + i) * seq_len, ids + (size_t)(done + i + 1) * seq_len, padded.begin() + (size_t)i * T);
+        VQ_HIP(hipMemcpyAsync(e->d_ids, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, e->stream));
+        VQ_TRY(forward(e, nullptr, cur, 0, e->d_out, nullptr, e->d_ids));
+        VQ_HIP(hipMemcpyAsync(out + (size_t)done * e->cfg.proj_dim, e->d_out, (size_t)cur * e->cfg.proj_dim * 4,
+                              hipMemcpyDeviceToHost, e->stream));
+        VQ_HIP(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+int vq_text_encoder_destroy(vq_text_encoder* e) { return vq_encoder_destroy(e); }
+
 int vq_encoder_destroy(vq_encoder* e) {
     if (!e) return 0;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -415,6 +560,7 @@ int vq_encoder_encode_u8_device(vq_encoder* e, const void* d_frames, int n, int 
                                 void* d_out_f16) {
     VQ_TRY(require_init());
     VQ_CHECK(e && d_frames && d_out_f32, "vq_encoder_encode_u8_device: null argument");
+    VQ_CHECK(!e->is_text, "vq_encoder_encode_u8_device: this is a text encoder handle");
     VQ_CHECK(n > 0 && n <= e->max_batch, "vq_encoder_encode_u8_device: n=%d outside (0, max_batch=%d]", n, e->max_batch);
     std::lock_guard<std::mutex> lk(e->mu);
     return forward(e, (const uint8_t*)d_frames, n, swap_rb, (float*)d_out_f32, (uint16_t*)d_out_f16);
@@ -423,6 +569,7 @@ int vq_encoder_encode_u8_device(vq_encoder* e, const void* d_frames, int n, int 
 int vq_encoder_encode_u8(vq_encoder* e, const uint8_t* frames, int n, int swap_rb, float* out) {
     VQ_TRY(require_init());
     VQ_CHECK(e && n >= 0 && (n == 0 || (frames && out)), "vq_encoder_encode_u8: bad argument");
+    VQ_CHECK(!e->is_text, "vq_encoder_encode_u8: this is a text encoder handle");
     std::lock_guard<std::mutex> lk(e->mu);
     const size_t fbytes = (size_t)e->cfg.image_size * e->cfg.image_size * 3;
     for (int done = 0; done < n; done += e->max_batch) {

@@ -148,6 +148,118 @@ def seeded_weights(cfg: VitConfig, seed: int) -> Dict[str, np.ndarray]:
     return out
 
 
+# ---- text tower (CLIPTextModel + text_projection; transformers modeling_clip.py:222-256, 500-586) ----
+@dataclass(frozen=True)
+class TextConfig:
+    vocab: int = 49408
+    max_positions: int = 77
+    hidden: int = 512
+    mlp: int = 2048
+    layers: int = 12
+    heads: int = 8
+    proj_dim: int = 512
+    eos_token_id: int = 49407
+    bos_token_id: int = 49406
+    ln_eps: float = 1e-5
+
+
+TEXT_B_32 = TextConfig()
+TEXT_L_14 = TextConfig(hidden=768, mlp=3072, heads=12, proj_dim=768)
+
+
+def text_weight_shapes(cfg: TextConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Canonical (HF state_dict name, shape) list of the text tower, in C-ABI order."""
+    h, m = cfg.hidden, cfg.mlp
+    out: List[Tuple[str, Tuple[int, ...]]] = [
+        ("text_model.embeddings.token_embedding.weight", (cfg.vocab, h)),
+        ("text_model.embeddings.position_embedding.weight", (cfg.max_positions, h)),
+    ]
+    for l in range(cfg.layers):
+        pre = f"text_model.encoder.layers.{l}."
+        out += [
+            (pre + "layer_norm1.weight", (h,)), (pre + "layer_norm1.bias", (h,)),
+            (pre + "self_attn.q_proj.weight", (h, h)), (pre + "self_attn.q_proj.bias", (h,)),
+            (pre + "self_attn.k_proj.weight", (h, h)), (pre + "self_attn.k_proj.bias", (h,)),
+            (pre + "self_attn.v_proj.weight", (h, h)), (pre + "self_attn.v_proj.bias", (h,)),
+            (pre + "self_attn.out_proj.weight", (h, h)), (pre + "self_attn.out_proj.bias", (h,)),
+            (pre + "layer_norm2.weight", (h,)), (pre + "layer_norm2.bias", (h,)),
+            (pre + "mlp.fc1.weight", (m, h)), (pre + "mlp.fc1.bias", (m,)),
+            (pre + "mlp.fc2.weight", (h, m)), (pre + "mlp.fc2.bias", (h,)),
+        ]
+    out += [
+        ("text_model.final_layer_norm.weight", (h,)),
+        ("text_model.final_layer_norm.bias", (h,)),
+        ("text_projection.weight", (cfg.proj_dim, h)),
+    ]
+    return out
+
+
+def seeded_text_weights(cfg: TextConfig, seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic fp32 text-tower weights (tensor i from PCG64([seed, 1000 + i]))."""
+    out: Dict[str, np.ndarray] = {}
+    for i, (name, shape) in enumerate(text_weight_shapes(cfg)):
+        rng = np.random.Generator(np.random.PCG64([int(seed), 1000 + i]))
+        z = rng.standard_normal(shape, dtype=np.float32)
+        if "layer_norm" in name and name.endswith(".weight"):
+            w = 1.0 + 0.1 * z
+        elif "layer_norm" in name and name.endswith(".bias"):
+            w = 0.05 * z
+        elif name.endswith(".bias"):
+            w = 0.02 * z
+        elif "token_embedding" in name:
+            w = 0.5 * z
+        elif "position_embedding" in name:
+            w = 0.1 * z
+        else:
+            w = z * (shape[1] ** -0.5)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def resolve_text_model(model_name: str) -> Tuple[TextConfig, Dict[str, np.ndarray], str]:
+    """``model_name`` -> (text config, weights, tokenizer directory or "").  Same rules as resolve_model."""
+    if model_name.startswith("seed:"):
+        parts = model_name.split(":")
+        arch = parts[2] if len(parts) > 2 else "b32"
+        cfg = {"b32": TEXT_B_32, "l14-336": TEXT_L_14}[arch]
+        return cfg, seeded_text_weights(cfg, int(parts[1])), ""
+    path = model_name
+    if not os.path.isdir(path):
+        root = os.environ.get("VQ_AMD_MODEL_DIR")
+        cand = os.path.join(root, os.path.basename(model_name)) if root else None
+        if cand and os.path.isdir(cand):
+            path = cand
+        else:
+            raise FileNotFoundError(f"model {model_name!r}: no local checkpoint directory (this build never downloads)")
+    cfg = TEXT_B_32
+    cj = os.path.join(path, "config.json")
+    if os.path.exists(cj):
+        import json
+        with open(cj) as f:
+            full = json.load(f)
+        t = full.get("text_config", {})
+        cfg = TextConfig(vocab=t.get("vocab_size", 49408), max_positions=t.get("max_position_embeddings", 77),
+                         hidden=t.get("hidden_size", 512), mlp=t.get("intermediate_size", 2048),
+                         layers=t.get("num_hidden_layers", 12), heads=t.get("num_attention_heads", 8),
+                         proj_dim=full.get("projection_dim", 512), eos_token_id=t.get("eos_token_id", 49407),
+                         bos_token_id=t.get("bos_token_id", 49406), ln_eps=t.get("layer_norm_eps", 1e-5))
+    want = dict(text_weight_shapes(cfg))
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path!r}")
+    from safetensors import safe_open
+    got: Dict[str, np.ndarray] = {}
+    for fn in files:
+        with safe_open(fn, framework="pt") as f:
+            for key in f.keys():
+                if key in want:
+                    got[key] = np.ascontiguousarray(f.get_tensor(key).float().numpy())
+    missing = [k for k in want if k not in got]
+    if missing:
+        raise KeyError(f"checkpoint {path!r} lacks {len(missing)} text tensors, e.g. {missing[:3]}")
+    return cfg, got, path
+
+
 def _load_dir(path: str, cfg: VitConfig) -> Dict[str, np.ndarray]:
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
     if not files:
