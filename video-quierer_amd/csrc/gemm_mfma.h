@@ -55,6 +55,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// logical tile index (0 .. tiles_m*tiles_n-1, no padding) -> (tile_m, tile_n) in 2-D blocked order:
+// m-block rows of bm tile rows; inside a row, n-blocks of bn tile columns; inside a block, n fastest.
+__device__ __forceinline__ bool tile_coords(int idx, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int bn = tiles_n < 8 ? tiles_n : 8;
+    const int bm = 32 / bn > 0 ? 32 / bn : 1;
+    const int row_tiles = bm * tiles_n;
+    const int bmi = idx / row_tiles, rem = idx - bmi * row_tiles;
+    const int bm_eff = min(bm, tiles_m - bmi * bm);
+    const int blk_tiles = bm_eff * bn;
+    const int bni = rem / blk_tiles, rem2 = rem - bni * blk_tiles;
+    const int bn_eff = min(bn, tiles_n - bni * bn);
+    tm = bmi * bm + rem2 / bn_eff;
+    tn = bni * bn + rem2 % bn_eff;
+    return true;
+}
 // Epilogue staging.  The MFMA result layout gives a lane 4 consecutive n for ONE m, so a wave-wide
 // store touches 16 different rows with 64-byte pieces; measured on the 256x256 kernel that store
 // pattern alone cost ~30-40 us per launch (39 MB of fp32 at <1 TB/s).  Instead every wave transposes

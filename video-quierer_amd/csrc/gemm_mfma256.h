@@ -29,6 +29,7 @@
 #pragma once
 #include "vq_common.h"
 #include "gemm_mfma.h"
+#include <cstdlib>
 
 namespace vq {
 
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
                        const uint16_t* __restrict__ W, int ldw,
                        int K, int tiles_n, Epi epi, unsigned long long* __restrict__ stamps = nullptr,
-                       int diag = 0 /* STAMP builds: bit0 skip DMA in the loop, bit1 skip ds_reads, bit2 skip MFMAs */) {
+                       int diag = 0 /* STAMP builds: bit0 skip DMA in the loop, bit1 skip ds_reads, bit2 skip MFMAs */,
+                       int order2d = 0 /* 1: 2-D blocked tile order (4x8 tiles per 32 consecutive workgroups) */) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,8 +58,10 @@ void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda,
     const int wr = wave >> 2, wc = wave & 3;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (wg / tiles_n) * G2_BM;
-    const int n0 = (wg % tiles_n) * G2_BN;
+    int tm = wg / tiles_n, tn = wg % tiles_n;
+    if (order2d) tile_coords(wg, (int)gridDim.x / tiles_n, tiles_n, tm, tn);
+    const int m0 = tm * G2_BM;
+    const int n0 = tn * G2_BN;
 
     // ---- LDS-DMA source pointers: wave w fills 1-KiB pieces 2w, 2w+1 of a half-tile ----
     const int srow = lane >> 3, sslot = lane & 7;
@@ -412,6 +416,12 @@ static int launch_gemm_tn256_ring_diag(hipStream_t st, const uint16_t* A, int ld
     return 0;
 }
 
+static inline int gemm_order2d() {          // $VQ_AMD_TILE2D=1: 2-D blocked tile order (experiment switch)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VQ_AMD_TILE2D"); v = (e && atoi(e) == 1) ? 1 : 0; }
+    return v;
+}
+
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                              int M, int N, int K, const Epi& epi) {
@@ -427,7 +437,7 @@ static int launch_gemm_tn256(hipStream_t st, const uint16_t* A, int lda, const u
     }
     const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
     hipLaunchKernelGGL((gemm_tn256_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
-                       A, lda, W, ldw, K, tiles_n, epi, (unsigned long long*)nullptr, 0);
+                       A, lda, W, ldw, K, tiles_n, epi, (unsigned long long*)nullptr, 0, gemm_order2d());
     VQ_HIP(hipGetLastError());
     return 0;
 }

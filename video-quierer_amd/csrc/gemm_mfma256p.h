@@ -27,21 +27,6 @@ namespace vq {
 constexpr int G2P_STRIP = 16 * 256;                         // 4 KiB per wave
 constexpr int G2P_LDS_BYTES = G2_LDS_BYTES + 8 * G2P_STRIP; // 160 KiB
 
-// logical tile index (0 .. tiles_m*tiles_n-1, no padding) -> (tile_m, tile_n) in 2-D blocked order:
-// m-block rows of bm tile rows; inside a row, n-blocks of bn tile columns; inside a block, n fastest.
-__device__ __forceinline__ bool tile_coords(int idx, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int bn = tiles_n < 8 ? tiles_n : 8;
-    const int bm = 32 / bn > 0 ? 32 / bn : 1;
-    const int row_tiles = bm * tiles_n;
-    const int bmi = idx / row_tiles, rem = idx - bmi * row_tiles;
-    const int bm_eff = min(bm, tiles_m - bmi * bm);
-    const int blk_tiles = bm_eff * bn;
-    const int bni = rem / blk_tiles, rem2 = rem - bni * blk_tiles;
-    const int bn_eff = min(bn, tiles_n - bni * bn);
-    tm = bmi * bm + rem2 / bn_eff;
-    tn = bni * bn + rem2 % bn_eff;
-    return true;
-}
 static inline int blocked_tile_slots(int tiles_m, int tiles_n) { return tiles_m * tiles_n; }
 
 template <bool IS_F16, class Epi>

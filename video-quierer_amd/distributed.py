@@ -64,9 +64,9 @@ def merge_topk(all_ids: torch.Tensor, all_dist: torch.Tensor, k: int) -> Tuple[t
 
 def sharded_topk(local_ids: torch.Tensor, local_dist: torch.Tensor, row_offset: int, k: int):
     """Local [Q, k] (shard-local row ids) → global exact [Q, k] on every rank."""
-    gids = torch.where(local_ids >= 0, local_ids + int(row_offset), local_ids)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return gids, local_dist
+        return (local_ids if row_offset == 0 else torch.where(local_ids >= 0, local_ids + int(row_offset), local_ids)), local_dist
+    gids = torch.where(local_ids >= 0, local_ids + int(row_offset), local_ids)
     world = dist.get_world_size()
     q, kk = gids.shape
     all_ids = torch.empty((world * q, kk), dtype=gids.dtype, device=gids.device)     # concatenated along dim 0
