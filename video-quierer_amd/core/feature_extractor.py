@@ -123,14 +123,24 @@ class FeatureExtractor:
         raise TypeError(f"unsupported image type {type(image)!r}")
 
     def _preprocess_batch(self, images: Sequence[ImageLike]):
-        """Reference :118-129 — here: one contiguous uint8 batch + a swap flag."""
+        """Reference :118-129 — here: one contiguous uint8 batch + a swap flag.  Like the reference, the
+        per-image work (here a 150 KB copy, plus a PIL resize for odd sizes) fans out over the thread pool
+        when there are more than 4 images (:123-124); numpy releases the GIL for the copies."""
         s = self.config.image_size
-        batch = np.empty((len(images), s, s, 3), dtype=np.uint8)
-        swaps = []
-        for i, im in enumerate(images):
-            arr, swap = self._preprocess_image(im)
-            batch[i] = arr
-            swaps.append(swap)
+        n = len(images)
+        batch = np.empty((n, s, s, 3), dtype=np.uint8)
+        swaps = [True] * n
+
+        def fill(lo, hi):
+            for i in range(lo, hi):
+                arr, swaps[i] = self._preprocess_image(images[i])
+                batch[i] = arr
+
+        if self.num_threads > 1 and n > 4:
+            step = -(-n // self.num_threads)
+            list(self.thread_pool.map(lambda lo: fill(lo, min(n, lo + step)), range(0, n, step)))
+        else:
+            fill(0, n)
         if all(swaps):
             return batch, True
         for i, sw in enumerate(swaps):          # mixed list: bring ndarray frames to RGB on the host
@@ -163,24 +173,36 @@ class FeatureExtractor:
             raise
 
     def extract_from_video_frames(self, frames_data: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
-        """Reference :179-209.  Frames are independent, so several ``batch_size``
-        slices are encoded in one device pass (up to ``device_batch`` frames); the
-        returned dicts, their order and keys are the reference's."""
+        """Reference :179-209.  Frames are independent, so several ``batch_size`` slices are encoded in one
+        device pass (up to ``device_batch`` frames) and the host-side assembly of the next pass overlaps the
+        GPU work of the current one; the returned dicts, their order and keys are the reference's."""
         if not frames_data:
             return []
         logger.info(f"Extracting features from {len(frames_data)} frames")
         start_time = time.time()
         step = max(self.batch_size, (self.device_batch // self.batch_size) * self.batch_size)
+        chunks = [frames_data[i:i + step] for i in range(0, len(frames_data), step)]
         results = []
-        for i in range(0, len(frames_data), step):
-            chunk = frames_data[i:i + step]
-            feats = self.extract_batch([fd["frame"] for fd in chunk])
-            now = time.time() - start_time
-            for fd, f in zip(chunk, feats):
-                r = fd.copy()
-                r["features"] = f
-                r["feature_extraction_time"] = now
-                results.append(r)
+        try:
+            with ThreadPoolExecutor(max_workers=1) as prefetch:
+                nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[0]])
+                for ci, chunk in enumerate(chunks):
+                    t0 = time.time()
+                    batch, swap = nxt.result()
+                    if ci + 1 < len(chunks):
+                        nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[ci + 1]])
+                    feats = self.model.encode(batch, swap_rb=swap)
+                    self.extraction_times.append(time.time() - t0)
+                    self.total_processed += len(chunk)
+                    now = time.time() - start_time
+                    for fd, f in zip(chunk, feats):
+                        r = fd.copy()
+                        r["features"] = f
+                        r["feature_extraction_time"] = now
+                        results.append(r)
+        except Exception as e:
+            logger.error(f"Feature extraction failed: {e}")
+            raise
         total = time.time() - start_time
         logger.info(f"Feature extraction completed: {len(results)} frames in {total:.2f}s "
                     f"({len(results) / max(total, 1e-9):.1f} fps)")
