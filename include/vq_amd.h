@@ -84,6 +84,11 @@ int vq_encoder_encode_u8(vq_encoder* enc, const uint8_t* frames, int n, int swap
  * d_out_f16 (optional, may be NULL) receives an fp16 copy of the embeddings. */
 int vq_encoder_encode_u8_device(vq_encoder* enc, const void* d_frames, int n, int swap_rb,
                                 void* d_out_f32, void* d_out_f16);
+/* Pinned host staging: two slots of max_batch frames each.  The host side assembles frames straight
+ * into a slot (one copy instead of two) and encodes from it; while slot s is being encoded (the call
+ * blocks only its own thread) another thread may fill slot 1-s.  n <= max_batch. */
+int vq_encoder_staging(vq_encoder* enc, int slot, uint8_t** host_ptr, size_t* bytes);
+int vq_encoder_encode_staged(vq_encoder* enc, int slot, int n, int swap_rb, float* out);
 int vq_encoder_synchronize(vq_encoder* enc);
 /* Run this handle's kernels on a caller-owned HIP stream (e.g. torch's current
  * stream, so RCCL collectives issued by torch order after the encode without a

@@ -47,6 +47,8 @@ SIGNATURES = {
     "vq_encoder_destroy": (c_int, [c_void_p]),
     "vq_encoder_encode_u8": (c_int, [c_void_p, POINTER(c_uint8), c_int, c_int, POINTER(c_float)]),
     "vq_encoder_encode_u8_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vq_encoder_staging": (c_int, [c_void_p, c_int, POINTER(POINTER(c_uint8)), POINTER(ctypes.c_size_t)]),
+    "vq_encoder_encode_staged": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_encoder_synchronize": (c_int, [c_void_p]),
     "vq_encoder_set_stream": (c_int, [c_void_p, c_void_p]),
     "vq_encoder_output_dim": (c_int, [c_void_p, POINTER(c_int)]),

@@ -122,13 +122,13 @@ class FeatureExtractor:
             return np.asarray(img, dtype=np.uint8), False
         raise TypeError(f"unsupported image type {type(image)!r}")
 
-    def _preprocess_batch(self, images: Sequence[ImageLike]):
+    def _preprocess_batch(self, images: Sequence[ImageLike], into: np.ndarray = None):
         """Reference :118-129 — here: one contiguous uint8 batch + a swap flag.  Like the reference, the
         per-image work (here a 150 KB copy, plus a PIL resize for odd sizes) fans out over the thread pool
         when there are more than 4 images (:123-124); numpy releases the GIL for the copies."""
         s = self.config.image_size
         n = len(images)
-        batch = np.empty((n, s, s, 3), dtype=np.uint8)
+        batch = np.empty((n, s, s, 3), dtype=np.uint8) if into is None else into[:n]     # `into`: pinned staging slot
         swaps = [True] * n
 
         def fill(lo, hi):
@@ -184,14 +184,16 @@ class FeatureExtractor:
         chunks = [frames_data[i:i + step] for i in range(0, len(frames_data), step)]
         results = []
         try:
+            stage = [self.model.staging(0), self.model.staging(1)]        # pinned slots, filled alternately
             with ThreadPoolExecutor(max_workers=1) as prefetch:
-                nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[0]])
+                nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[0]], stage[0])
                 for ci, chunk in enumerate(chunks):
                     t0 = time.time()
                     batch, swap = nxt.result()
                     if ci + 1 < len(chunks):
-                        nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[ci + 1]])
-                    feats = self.model.encode(batch, swap_rb=swap)
+                        nxt = prefetch.submit(self._preprocess_batch, [fd["frame"] for fd in chunks[ci + 1]],
+                                              stage[(ci + 1) & 1])
+                    feats = self.model.encode_staged(ci & 1, len(chunk), swap_rb=swap)
                     self.extraction_times.append(time.time() - t0)
                     self.total_processed += len(chunk)
                     now = time.time() - start_time

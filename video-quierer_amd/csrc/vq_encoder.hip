@@ -59,6 +59,8 @@ struct vq_encoder {
     uint8_t* d_frames = nullptr;
     float *x = nullptr, *d_out = nullptr;
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned staging slots (lazy)
+    float* h_out_stage = nullptr;               // pinned result buffer
     int run_layers = -1;
     int last_n = 0;
     bool is_text = false;       // CLIP text tower (vq_text_encoder_*): token embedding, causal attention, EOS pooling
@@ -546,6 +548,8 @@ int vq_encoder_destroy(vq_encoder* e) {
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->arena.base) (void)hipFree(e->arena.base);
+    for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
+    if (e->h_out_stage) (void)hipHostFree(e->h_out_stage);
     delete e;
     return 0;
 }
@@ -580,6 +584,32 @@ int vq_encoder_encode_u8(vq_encoder* e, const uint8_t* frames, int n, int swap_r
                               hipMemcpyDeviceToHost, e->stream));
         VQ_HIP(hipStreamSynchronize(e->stream));
     }
+    return 0;
+}
+
+int vq_encoder_staging(vq_encoder* e, int slot, uint8_t** host_ptr, size_t* bytes) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && !e->is_text && host_ptr && bytes && (slot == 0 || slot == 1), "vq_encoder_staging: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t sz = (size_t)e->max_batch * e->cfg.image_size * e->cfg.image_size * 3;
+    if (!e->h_stage[slot]) VQ_HIP(hipHostMalloc((void**)&e->h_stage[slot], sz));
+    if (!e->h_out_stage) VQ_HIP(hipHostMalloc((void**)&e->h_out_stage, (size_t)e->max_batch * e->cfg.proj_dim * 4));
+    *host_ptr = e->h_stage[slot];
+    *bytes = sz;
+    return 0;
+}
+
+int vq_encoder_encode_staged(vq_encoder* e, int slot, int n, int swap_rb, float* out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && !e->is_text && out && (slot == 0 || slot == 1) && e->h_stage[slot], "vq_encoder_encode_staged: bad argument / slot not staged");
+    VQ_CHECK(n > 0 && n <= e->max_batch, "vq_encoder_encode_staged: n=%d outside (0, max_batch=%d]", n, e->max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t fbytes = (size_t)e->cfg.image_size * e->cfg.image_size * 3;
+    VQ_HIP(hipMemcpyAsync(e->d_frames, e->h_stage[slot], n * fbytes, hipMemcpyHostToDevice, e->stream));
+    VQ_TRY(forward(e, e->d_frames, n, swap_rb, e->d_out, nullptr));
+    VQ_HIP(hipMemcpyAsync(e->h_out_stage, e->d_out, (size_t)n * e->cfg.proj_dim * 4, hipMemcpyDeviceToHost, e->stream));
+    VQ_HIP(hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_out_stage, (size_t)n * e->cfg.proj_dim * 4);
     return 0;
 }
 

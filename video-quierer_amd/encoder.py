@@ -50,6 +50,21 @@ class VitEncoder:
                                                         int(bool(swap_rb)), _lib.fptr(out)))
         return out
 
+    # -- pinned staging (host frames without the extra copy) --------------------
+    def staging(self, slot: int) -> np.ndarray:
+        """uint8 view [max_batch,S,S,3] of pinned staging slot 0/1 (library-owned, valid until close())."""
+        ptr = POINTER(c_uint8)()
+        size = ctypes.c_size_t(0)
+        _lib.check(_lib.load().vq_encoder_staging(self._h, int(slot), ctypes.byref(ptr), ctypes.byref(size)))
+        s = self.cfg.image_size
+        arr = np.ctypeslib.as_array(ptr, shape=(size.value,))
+        return arr.reshape(self.max_batch, s, s, 3)
+
+    def encode_staged(self, slot: int, n: int, swap_rb: bool = True) -> np.ndarray:
+        out = np.empty((n, self.cfg.proj_dim), dtype=np.float32)
+        _lib.check(_lib.load().vq_encoder_encode_staged(self._h, int(slot), int(n), int(bool(swap_rb)), _lib.fptr(out)))
+        return out
+
     # -- device buffers (pointers, e.g. torch.Tensor.data_ptr()) ----------------
     def encode_device(self, d_frames: int, n: int, d_out_f32: int, d_out_f16: int = 0, swap_rb: bool = True) -> None:
         """Asynchronous on the encoder's stream; call synchronize() before reading."""
