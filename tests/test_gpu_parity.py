@@ -522,3 +522,68 @@ def test_feature_extractor_text_ids(gpu_lib):
     both = fx.extract_text_features_from_ids(np.stack([ids, ids[::-1].copy()]))
     assert both.shape == (2, 512) and np.allclose(both[0], v, atol=1e-6)
     fx.thread_pool.shutdown()
+
+
+# ------------------------------------------------------------------ BASELINE full sizes through size-independent properties
+def test_config3_full_size_properties(gpu_lib):
+    """configs[2]: 1,000,000 x 512 matrix.  Too large for the CPU oracle in seconds, so: (a) self-queries
+    return their own row first at distance ~0, (b) lists are sorted by (distance, id), (c) the fp16-scan
+    result is bit-identical to the independent exact fp32-master scan on a query subset, (d) every query is
+    accounted for by the proof statistics."""
+    import torch
+    from video_quierer_amd.indexes.hnsw import MODE_EXACT, MODE_FP16, OptimizedHNSWIndex
+    n, d = 1_000_000, 512
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(123)
+    idx = OptimizedHNSWIndex(dimension=d)
+    for c0 in range(0, n, 250_000):
+        blk = torch.randn((250_000, d), device=dev, generator=g)
+        torch.cuda.synchronize()
+        idx.add_device(blk.data_ptr(), 250_000, range(c0, c0 + 250_000), normalize=True)
+        idx.synchronize()
+    assert idx.size() == n
+    rows = torch.tensor([0, 1, 127, 128, 2047, 2048, 499_999, 999_999] + list(range(31_337, 31_337 + 120)), device=dev)
+    # fetch those rows back through a search-independent path: regenerate the blocks is costly -> query by row vectors
+    # taken from an exact search of one-hot style probes is circular; instead use export of a small index slice:
+    probe = torch.randn((64, d), device=dev, generator=g)
+    probe = probe / probe.norm(dim=1, keepdim=True)
+    ids16 = torch.empty((64, 10), dtype=torch.int32, device=dev); d16 = torch.empty((64, 10), device=dev)
+    idsx = torch.empty((64, 10), dtype=torch.int32, device=dev); dx = torch.empty((64, 10), device=dev)
+    torch.cuda.synchronize()
+    idx.search_device(probe.data_ptr(), 64, 10, ids16.data_ptr(), d16.data_ptr(), mode=MODE_FP16); idx.synchronize()
+    st = idx.last_search_stats()
+    idx.search_device(probe.data_ptr(), 64, 10, idsx.data_ptr(), dx.data_ptr(), mode=MODE_EXACT); idx.synchronize()
+    assert torch.equal(ids16, idsx) and torch.equal(d16, dx)                  # (c) two independent code paths, same bits
+    assert st["verified"] + st["rescanned"] + st["exact_fallback"] == 64      # (d)
+    dd = d16.cpu().numpy(); ii = ids16.cpu().numpy()
+    assert np.all(np.diff(dd, axis=1) >= 0) and np.all((ii >= 0) & (ii < n))  # (b)
+    # (a) self-queries: use the top-1 rows of the probes as queries — each must return itself at distance <= 1e-6.
+    # Their vectors come from a second, tiny index built from the SAME generator stream position? No: take them from
+    # the exact search path by asking for k=1 neighbours of the row's own vector, obtained via the index export of
+    # a prefix copy.
+    small = OptimizedHNSWIndex(dimension=d)
+    g2 = torch.Generator(device=dev); g2.manual_seed(123)
+    blk = torch.randn((250_000, d), device=dev, generator=g2)               # same stream -> identical first block
+    torch.cuda.synchronize()
+    small.add_device(blk.data_ptr(), 4096, range(4096), normalize=True); small.synchronize()
+    first = small._export()                                                   # rows 0..4095 of the big index, bit for bit
+    res = idx.search_batch(list(first[:256]), 3)
+    assert [r[0]["id"] for r in res] == list(range(256))
+    assert max(abs(float(r[0]["distance"])) for r in res) <= 1e-6
+    idx.close(); small.close()
+
+
+def test_config2_batching_invariance(gpu_lib, b32_weights):
+    """configs[1]: embeddings must not depend on how frames are grouped into device passes: 1,000 frames in
+    passes of 256 vs passes of 100 give identical bits (each output row is the same MFMA/K sequence whatever
+    tile it lands in), and the run is deterministic."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    frames = synth_frames(1000, seed=77)
+    a = VitEncoder(VIT_B_32, b32_weights, max_batch=256)
+    b = VitEncoder(VIT_B_32, b32_weights, max_batch=100)
+    ea, eb = a.encode(frames), b.encode(frames)
+    assert np.array_equal(ea, a.encode(frames))
+    assert np.array_equal(ea, eb)
+    assert np.allclose(np.linalg.norm(ea, axis=1), 1.0, atol=1e-5)
+    a.close(); b.close()
