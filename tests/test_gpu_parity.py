@@ -542,9 +542,6 @@ def test_config3_full_size_properties(gpu_lib):
         idx.add_device(blk.data_ptr(), 250_000, range(c0, c0 + 250_000), normalize=True)
         idx.synchronize()
     assert idx.size() == n
-    rows = torch.tensor([0, 1, 127, 128, 2047, 2048, 499_999, 999_999] + list(range(31_337, 31_337 + 120)), device=dev)
-    # fetch those rows back through a search-independent path: regenerate the blocks is costly -> query by row vectors
-    # taken from an exact search of one-hot style probes is circular; instead use export of a small index slice:
     probe = torch.randn((64, d), device=dev, generator=g)
     probe = probe / probe.norm(dim=1, keepdim=True)
     ids16 = torch.empty((64, 10), dtype=torch.int32, device=dev); d16 = torch.empty((64, 10), device=dev)
@@ -557,10 +554,8 @@ def test_config3_full_size_properties(gpu_lib):
     assert st["verified"] + st["rescanned"] + st["exact_fallback"] == 64      # (d)
     dd = d16.cpu().numpy(); ii = ids16.cpu().numpy()
     assert np.all(np.diff(dd, axis=1) >= 0) and np.all((ii >= 0) & (ii < n))  # (b)
-    # (a) self-queries: use the top-1 rows of the probes as queries — each must return itself at distance <= 1e-6.
-    # Their vectors come from a second, tiny index built from the SAME generator stream position? No: take them from
-    # the exact search path by asking for k=1 neighbours of the row's own vector, obtained via the index export of
-    # a prefix copy.
+    # (a) self-queries.  The first rows of the big index are reproduced bit for bit in a small second index
+    # (same generator seed -> identical first block, same device normalisation) and exported from there.
     small = OptimizedHNSWIndex(dimension=d)
     g2 = torch.Generator(device=dev); g2.manual_seed(123)
     blk = torch.randn((250_000, d), device=dev, generator=g2)               # same stream -> identical first block
