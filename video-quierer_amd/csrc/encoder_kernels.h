@@ -48,8 +48,11 @@ struct EpiBiasQuickGeluH16 {
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         const float4 b = *(const float4*)(bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        // x*sigmoid(1.702x) = x * rcp(1 + 2^(-1.702*log2(e)*x)): v_exp_f32 is a base-2 exponential and v_rcp_f32
+        // replaces the IEEE division sequence (1 ulp each; the result is rounded to 16 bits right after)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+        for (int i = 0; i < 4; ++i)
+            v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[i]));
         *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
     }
 };
