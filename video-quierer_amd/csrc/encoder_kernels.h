@@ -30,14 +30,17 @@ __host__ __device__ inline uint16_t to_h16(float f) {
     else return f32_to_bf16_rne(f);
 }
 
+__device__ __forceinline__ f32x4 ld4(const float* p) { const float4 t = *(const float4*)p; return f32x4{t.x, t.y, t.z, t.w}; }
+
 // y = acc + bias  -> 16-bit                    (E6: fused q|k|v projection)
 template <bool F16>
 struct EpiBiasH16 {
     uint16_t* out; int ldo; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        const float4 b = *(const float4*)(bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
+    static constexpr bool kLoads = false;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4) const {
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v + b);
     }
 };
 
@@ -45,9 +48,11 @@ struct EpiBiasH16 {
 template <bool F16>
 struct EpiBiasQuickGeluH16 {
     uint16_t* out; int ldo; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        const float4 b = *(const float4*)(bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    static constexpr bool kLoads = false;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4) const {
+        v = v + b;
         // x*sigmoid(1.702x) = x * rcp(1 + 2^(-1.702*log2(e)*x)): v_exp_f32 is a base-2 exponential and v_rcp_f32
         // replaces the IEEE division sequence (1 ulp each; the result is rounded to 16 bits right after)
 #pragma unroll
@@ -60,25 +65,24 @@ struct EpiBiasQuickGeluH16 {
 // x += acc + bias   (fp32 residual stream)      (E5: out_proj / fc2 + residual)
 struct EpiBiasResidualF32 {
     float* x; int ldx; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        const float4 b = *(const float4*)(bias + n);
-        float4* p = (float4*)(x + (size_t)m * ldx + n);
-        float4 r = *p;
-        r.x += v[0] + b.x; r.y += v[1] + b.y; r.z += v[2] + b.z; r.w += v[3] + b.w;
-        *p = r;
+    static constexpr bool kLoads = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const { return ld4(x + (size_t)m * ldx + n); }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
+        *(f32x4*)(x + (size_t)m * ldx + n) = r + v + b;
     }
 };
 
 // Last block, CLS rows only: GEMM row m = image m -> residual row m*tokens; rows >= m_valid are padding
 struct EpiBiasResidualClsF32 {
     float* x; int hidden; int tokens; const float* bias; int m_valid;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        if (m >= m_valid) return;
-        const float4 b = *(const float4*)(bias + n);
-        float4* p = (float4*)(x + (size_t)m * tokens * hidden + n);
-        float4 r = *p;
-        r.x += v[0] + b.x; r.y += v[1] + b.y; r.z += v[2] + b.z; r.w += v[3] + b.w;
-        *p = r;
+    static constexpr bool kLoads = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const {
+        return m < m_valid ? ld4(x + (size_t)m * tokens * hidden + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
+        if (m < m_valid) *(f32x4*)(x + (size_t)m * tokens * hidden + n) = r + v + b;
     }
 };
 
@@ -86,13 +90,17 @@ struct EpiBiasResidualClsF32 {
 // x = acc + folded_bias + position_embedding[1+p]          (E3)
 struct EpiPatchEmbedF32 {
     float* x; int hidden; const float* bias; const float* pos; int patches; int tokens; int m_valid;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    static constexpr bool kLoads = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const {
+        if (m >= m_valid) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int p = m % patches;
+        return ld4(pos + (size_t)(1 + p) * hidden + n);
+    }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4 pp) const {
         if (m >= m_valid) return;
-        const int b = m / patches, p = m - b * patches;
-        const float4 bb = *(const float4*)(bias + n);
-        const float4 pp = *(const float4*)(pos + (size_t)(1 + p) * hidden + n);
-        float4 r = {v[0] + bb.x + pp.x, v[1] + bb.y + pp.y, v[2] + bb.z + pp.z, v[3] + bb.w + pp.w};
-        *(float4*)(x + ((size_t)b * tokens + 1 + p) * hidden + n) = r;
+        const int bimg = m / patches, p = m - bimg * patches;
+        *(f32x4*)(x + ((size_t)bimg * tokens + 1 + p) * hidden + n) = v + b + pp;
     }
 };
 

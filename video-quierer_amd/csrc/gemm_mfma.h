@@ -79,13 +79,27 @@ __device__ __forceinline__ bool tile_coords(int idx, int tiles_m, int tiles_n, i
 constexpr int EPI_ROW_BYTES = 272;
 constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
 
+// Epilogue functor interface (row-contiguous calls; n is the same for every call of a lane):
+//   f32x4 bias_at(n)                  loaded once per lane
+//   static constexpr bool kLoads      whether the epilogue reads memory per element (residual RMW, position emb.)
+//   f32x4 load(m, n)                  that read; all 8 reads of a pass are issued BEFORE the first store, because a
+//                                     load->add->store chain per element serialises on the L2 round trip (measured:
+//                                     32 dependent round trips per lane in the residual GEMMs)
+//   void  store(m, n, acc, bias, loaded)
 template <int MI, class Epi>      // wave tile = MI*16 rows x 64 cols; acc[mi][ni] = C[16mi + lane&15][16ni + 4(lane>>4) ..+3]
 __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI][4], int m_wave0, int n_wave0,
                                               int lane, const Epi& epi) {
     const int frow = lane & 15, fgrp = lane >> 4;
     const int rrow = lane >> 4, rcol = lane & 15;
+    const int n = n_wave0 + rcol * 4;
+    const f32x4 bias = epi.bias_at(n);
 #pragma unroll
     for (int pass = 0; pass < MI / 2; ++pass) {
+        f32x4 loaded[8];
+        if constexpr (Epi::kLoads) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) loaded[it] = epi.load(m_wave0 + pass * 32 + it * 4 + rrow, n);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -96,7 +110,7 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + rrow;
             const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
-            epi(m_wave0 + pass * 32 + row, n_wave0 + rcol * 4, v);
+            epi.store(m_wave0 + pass * 32 + row, n, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
 }

@@ -144,9 +144,16 @@ void gemm_tn256p_kernel(const uint16_t* __restrict__ A, int lda,
     char* strip = smem + G2_LDS_BYTES + wave * G2P_STRIP;
     const int rrow = lane >> 4, rcol = lane & 15;
     auto epilogue_half = [&](int hm, int m0, int n0) __attribute__((always_inline)) {
+        const int ncol = n0 + wc * 64 + rcol * 4;
+        const f32x4 bias = epi.bias_at(ncol);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                 // one 16-row m tile per pass
             const int mi = hm * 4 + i;
+            f32x4 loaded[4];
+            if constexpr (Epi::kLoads) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) loaded[it] = epi.load(m0 + wr * 128 + mi * 16 + it * 4 + rrow, ncol);
+            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 *(f32x4*)(strip + frow * 256 + (((ni * 4 + fgrp) ^ frow) & 15) * 16) = acc[mi][ni];
@@ -156,7 +163,7 @@ void gemm_tn256p_kernel(const uint16_t* __restrict__ A, int lda,
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + rrow;
                 const f32x4 v = *(const f32x4*)(strip + row * 256 + ((rcol ^ row) & 15) * 16);
-                epi(m0 + wr * 128 + mi * 16 + row, n0 + wc * 64 + rcol * 4, v);
+                epi.store(m0 + wr * 128 + mi * 16 + row, ncol, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     };
