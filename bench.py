@@ -60,6 +60,7 @@ def gemm_flops(cls, rows, cfg):
         "gemm_out_proj_residual": 2 * rows * h * h,
         "gemm_fc1_quickgelu": 2 * rows * m * h,
         "gemm_fc2_residual": 2 * rows * h * m,
+        "attention": 4 * rows * cfg.tokens * h,          # QK^T and PV: 2 * (n*heads) * T*T*d_h * 2 FLOP
     }.get(cls)
 
 
@@ -172,7 +173,7 @@ def main():
         # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/, gfx950 correction applied there)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")) as f:
                 traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
         except OSError:
             pass
@@ -180,7 +181,7 @@ def main():
             ach = fl / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12,
                                "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_BF16, "traffic": traffic,
-                               "traffic_source": "profiles/r01b_pmc_traffic.json (rocprofv3 PMC, batch 256)",
+                               "traffic_source": "profiles/r01d_pmc_traffic.json (rocprofv3 PMC, batch 256)",
                                "avg_launch_ms": avg_ms, "flops_per_launch": fl}
         else:
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",

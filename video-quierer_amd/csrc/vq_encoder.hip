@@ -22,7 +22,7 @@ enum EncClass { C_PATCHIFY = 0, C_GEMM_PATCH, C_EMBED_FINISH, C_LAYERNORM, C_GEM
                 C_GEMM_OUT, C_GEMM_FC1, C_GEMM_FC2, C_POOL };
 static const char* kEncClassNames[VQ_ENC_NCLASS] = {
     "patchify_u8", "gemm_patch_embed", "embed_finish_ln", "layernorm_bf16", "gemm_qkv",
-    "attention_t64", "gemm_out_proj_residual", "gemm_fc1_quickgelu", "gemm_fc2_residual", "pool_project"};
+    "attention", "gemm_out_proj_residual", "gemm_fc1_quickgelu", "gemm_fc2_residual", "pool_project"};
 
 struct LayerW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_qkv, *b_out, *b_fc1, *b_fc2;
