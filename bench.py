@@ -245,6 +245,31 @@ def main():
             sp = idx.profile_end()
             srch["kernel_classes"] = {k_: v for k_, v in sp.items() if v["launches"]}
             srch["last_search_stats"] = idx.last_search_stats()
+        # CPU baseline for the search leg (rank 0, N=1 only): the exact C oracle (OpenMP) on a bounded query
+        # sample over the SAME matrix, and the pure-Python HNSW restatement (what the reference runs) at N=2000
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import hnsw_oracle, knn_oracle
+            import random as _random
+            host_rows = idx._export()
+            ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
+            os.environ["OMP_NUM_THREADS"] = str(ncores)
+            qs_host = q[:32].cpu().numpy()
+            t0 = time.perf_counter()
+            knn_oracle.topk(host_rows, qs_host, k)
+            ct = time.perf_counter() - t0
+            srch["cpu_baseline"] = {"value": 32 / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
+                                    "sample": f"32 of the {nq} queries, exact top-{k} over all {n_rows} rows, C oracle "
+                                              f"(oracle/knn_oracle.c, fp64-chain dot, OpenMP), {ct:.2f}s"}
+            hn = 2000
+            _random.seed(0)
+            ho = hnsw_oracle.HnswOracle(args.search_dim)
+            t0 = time.perf_counter(); ho.add_batch(list(host_rows[:hn]), list(range(hn))); tb = time.perf_counter() - t0
+            t0 = time.perf_counter(); [ho.search(v, k) for v in qs_host]; tq = time.perf_counter() - t0
+            srch["cpu_hnsw_port"] = {"rows": hn, "insert_ms": 1e3 * tb / hn, "queries_per_s": 32 / tq, "cores": 1,
+                                     "note": "pure-Python restatement of the reference's HNSW (oracle/hnsw_oracle.py), "
+                                             "defaults M=16 efC=200 ef=50; the reference cannot be built at 1M rows in "
+                                             "bounded time (~3 ms per insert and rising)"}
+            del host_rows
         out["search"] = srch
         idx.close()
 
