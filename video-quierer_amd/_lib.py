@@ -98,8 +98,13 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is None:
             if not os.path.exists(LIB_PATH):
-                raise VqError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "(there is no CPU fallback for this path)")
+                # a fresh checkout has sources only: build in place if the toolchain is here (hipcc
+                # cross-compiles gfx950 without a GPU); never substitute anything else for the library
+                try:
+                    build()
+                except Exception as e:
+                    raise VqError(f"{LIB_PATH} is missing and building it failed ({e}); "
+                                  "there is no CPU fallback for this path") from e
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)      # AttributeError here = header/library mismatch
