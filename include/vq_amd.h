@@ -171,8 +171,10 @@ int vq_index_clear(vq_index* idx);
  *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row).
  * queries [nq][dim] must already be L2-normalised (the wrapper does query /
  * ||query|| with numpy, hnsw.py:250).  ids/dist are [nq][k]; unused slots
- * (k > size) are id -1 / dist +inf.  mode: 0 auto, 1 exact fp32-master scan,
- * 2 fp16 MFMA scan + exact re-score. */
+ * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 32), 1 exact
+ * fp32-master scan, 2 fp16 MFMA scan + exact re-score with proof (unproven queries are redone by the
+ * exact scan).  The fp16 path reads its per-query outcome flags back, so vq_index_search_device returns
+ * with the stream drained in that mode; the exact mode is fully asynchronous. */
 int vq_index_search(vq_index* idx, const float* queries, int nq, int k, int mode,
                     int32_t* ids, float* dist);
 int vq_index_search_device(vq_index* idx, const void* d_queries_f32, int nq, int k, int mode,
