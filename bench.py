@@ -96,7 +96,8 @@ def main():
     # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype) for _ in range(nstreams)]
+    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=nstreams > 1)
+            for _ in range(nstreams)]
     for e_, s_ in zip(encs, streams):
         e_.set_stream(s_.cuda_stream)
     enc, stream = encs[0], streams[0]
@@ -253,7 +254,7 @@ def main():
             host_rows = idx._export()
             ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
             os.environ["OMP_NUM_THREADS"] = str(ncores)
-            ncpu_q = 1024
+            ncpu_q = 512
             qs_host = q[:ncpu_q].cpu().numpy()
             t0 = time.perf_counter()
             knn_oracle.topk(host_rows, qs_host, k)

@@ -17,11 +17,11 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])    # 1 = 128x128, 2 = 256x256 four-phase, 3 = ring, 4 = persistent
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])    # 1 = 128x128, 2 = 256x256 four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring
 def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(0)
-    m, n, k = 512, 256, 384
+    m, n, k = (640 if kernel == 5 else 512), 256, 384
     a = np.zeros((m, k), np.float32)
     a[np.arange(m), np.arange(m) % k] = 1.0                  # row i picks column i % k  ("A = I" check)
     w = rng.integers(-8, 9, (n, k)).astype(np.float32)       # asymmetric W catches a transposed C write
@@ -31,17 +31,17 @@ def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     for f16 in (False, True):
         assert np.array_equal(debug_gemm(a, w, use_f16=f16, kernel=kernel), a @ w.T)   # small ints: exact
     # many k-tiles and several workgroups per XCD: exercises the steady-state pipeline and the tile remap
-    m, n, k = 1024, 768, 3072
+    m, n, k = (960 if kernel == 5 else 1024), 768, 3072
     a = rng.integers(-2, 3, (m, k)).astype(np.float32)
     w = rng.integers(-2, 3, (n, k)).astype(np.float32)
     assert np.array_equal(debug_gemm(a, w, kernel=kernel), a @ w.T)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
 def test_gemm_mfma_random(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(1)
-    m, n, k = 512, 256, 3072
+    m, n, k = (640 if kernel == 5 else 512), 256, 3072
     a = rng.standard_normal((m, k)).astype(np.float32)
     w = rng.standard_normal((n, k)).astype(np.float32)
     ab = torch.from_numpy(a).bfloat16().float().numpy()

@@ -113,6 +113,23 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
             epi.store(m_wave0 + pass * 32 + row, n, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
+    if constexpr (MI & 1) {               // odd block count: a last pass over 16 rows
+        constexpr int base = (MI - 1) * 16;
+        f32x4 loaded[4];
+        if constexpr (Epi::kLoads) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) loaded[it] = epi.load(m_wave0 + base + it * 4 + rrow, n);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            *(f32x4*)(strip + frow * EPI_ROW_BYTES + (ni * 16 + fgrp * 4) * 4) = acc[MI - 1][ni];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 4 + rrow;
+            const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
+            epi.store(m_wave0 + base + row, n, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    }
 }
 
 template <bool IS_F16, class Epi>

@@ -68,7 +68,7 @@ struct vq_encoder {
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
-    int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles
+    int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles, 6 = auto without 160-row tiles
     // profiling
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -138,6 +138,11 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         return (r256 - r128) * 16 <= r128 ? r256 : r128;
     };
     const int rows_gemm = pad_rows(rows);
+    // per-GEMM row count: 160-row tiles where they occupy more CUs than 256-row tiles (gemm_mfma160.h)
+    auto gemm_rows = [&](int N, int K) {
+        const int r160 = (int)round_up(rows, G5_BM);
+        return (e->gemm_force == 0 && gemm_use160() && r160 <= e->rows_pad && prefer_tn160(r160, N, K)) ? r160 : rows_gemm;
+    };
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
 
@@ -184,7 +189,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
             Prof p(e, C_GEMM_QKV);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_qkv, H, gemm_rows(3 * H, H), 3 * H, H,
                                             EpiBiasH16<F16>{e->qkv, 3 * H, L.b_qkv}, e->gemm_force)));
         }
         {
@@ -239,7 +244,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {
             Prof p(e, C_GEMM_OUT);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, rows_gemm, H, H,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
                                             EpiBiasResidualF32{e->x, H, L.b_out}, e->gemm_force)));
         }
         {
@@ -249,12 +254,12 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // E7: fc1 + quick_gelu
             Prof p(e, C_GEMM_FC1);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_fc1, H, gemm_rows(c.mlp, H), c.mlp, H,
                                             EpiBiasQuickGeluH16<F16>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
         }
         {
             Prof p(e, C_GEMM_FC2);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, rows_gemm, H, c.mlp,
+            VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
                                             EpiBiasResidualF32{e->x, H, L.b_fc2}, e->gemm_force)));
         }
     }
@@ -313,13 +318,14 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     const int patch_k = (int)round_up(patch_k_raw, 2 * G2_BK);     // zero-padded K (ViT-L/14: 588 -> 640)
 
     vq_encoder* e = new vq_encoder();
+    if (flags & VQ_ENC_CONCURRENT) e->gemm_force = 6;        // auto, without the 160-row tiles
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     if (const char* at = getenv("VQ_AMD_ATTN")) e->attn_simple = !strcmp(at, "simple");
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->fp16 = (flags & VQ_ENC_FP16) != 0;
     if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
-    e->rows_pad = round_up((int64_t)max_batch * tokens, 256);
+    e->rows_pad = round_up((int64_t)max_batch * tokens + (G5_BM - 1), 256);     // room for 256- and 160-row padding
     e->prow_pad = round_up((int64_t)max_batch * patches, 256);
     auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
 
@@ -434,7 +440,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->cfg = vq_vit_config{0, 0, t.hidden, t.mlp, t.layers, t.heads, t.proj_dim, t.ln_eps};
     e->tokens = t.max_positions; e->patches = 0; e->grid = 0; e->patch_k = 0; e->max_batch = max_batch;
     e->vocab = t.vocab; e->eos_id = t.eos_token_id;
-    e->rows_pad = round_up((int64_t)max_batch * e->tokens, 256);
+    e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     e->fp16 = (flags & VQ_ENC_FP16) != 0;

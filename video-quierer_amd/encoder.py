@@ -16,7 +16,8 @@ from .weights import VitConfig, weight_names
 
 class VitEncoder:
     def __init__(self, cfg: VitConfig, weights: Dict[str, np.ndarray], max_batch: int = 256,
-                 device: Optional[int] = None, compute_dtype: str = "bf16"):
+                 device: Optional[int] = None, compute_dtype: str = "bf16", concurrent: bool = False):
+        """concurrent: several handles are kept busy on separate streams (VQ_ENC_CONCURRENT in vq_amd.h)."""
         if compute_dtype not in ("bf16", "fp16"):
             raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
         self.compute_dtype = compute_dtype
@@ -31,7 +32,8 @@ class VitEncoder:
                                cfg.proj_dim, cfg.ln_eps)
         h = c_void_p()
         _lib.check(lib.vq_encoder_create_ex(ctypes.byref(ccfg), ptrs, len(names), self.max_batch,
-                                            1 if compute_dtype == "fp16" else 0, ctypes.byref(h)))
+                                            (1 if compute_dtype == "fp16" else 0) | (2 if concurrent else 0),
+                                            ctypes.byref(h)))
         self._h = h
         self._keep = None          # the library has its own device copies now
         self.output_dim = cfg.proj_dim
