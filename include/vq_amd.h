@@ -200,6 +200,45 @@ const char* vq_index_profile_class_name(int cls);
  * full exact scan */
 int vq_index_last_search_stats(vq_index* idx, int64_t* stats /*[3]*/);
 
+/* ------------------------------------------------------------------ frame preprocessing
+ * The resize in front of the encoder, bit-identical to Pillow's 8-bit separable resample
+ * (Pillow src/libImaging/Resample.c), which is what the reference runs in two places:
+ *   - transforms.Resize((224, 224)) on a PIL image, feature_extractor.py:54-61, :105-116
+ *       -> filter BILINEAR, out 224x224, crop = the whole resized frame;
+ *   - CLIPProcessor on the live path, video_search_overhaul.py:129-135, :218-221, :283-289
+ *       -> filter BICUBIC, short edge to 224, centre crop 224x224 (vq_clip_processor_geometry).
+ * Frames are uint8 [n][h][w][3] of one size; channel order is untouched (resize is per channel).
+ * The resized frame is out_h x out_w; only the window crop_h x crop_w at (crop_top, crop_left) is produced:
+ * out [n][crop_h][crop_w][3]. */
+#define VQ_RESAMPLE_BILINEAR 2      /* PIL.Image.BILINEAR */
+#define VQ_RESAMPLE_BICUBIC 3       /* PIL.Image.BICUBIC */
+typedef struct vq_resampler vq_resampler;
+int vq_resampler_create(vq_resampler** out);
+int vq_resampler_destroy(vq_resampler* r);
+int vq_resampler_set_stream(vq_resampler* r, void* hip_stream);
+int vq_resampler_synchronize(vq_resampler* r);
+/* Host frames in; host result out, or (out == NULL) left in the handle's device buffer for
+ * vq_encoder_encode_u8_device.  Returns when the result is complete. */
+int vq_resampler_run_u8(vq_resampler* r, const uint8_t* frames, int n, int h, int w, int filter,
+                        int out_h, int out_w, int crop_top, int crop_left, int crop_h, int crop_w, uint8_t* out);
+/* Same for n separately allocated frames of one size (a Python list of ndarray frames). */
+int vq_resampler_run_u8_list(vq_resampler* r, const uint8_t* const* frames, int n, int h, int w, int filter,
+                             int out_h, int out_w, int crop_top, int crop_left, int crop_h, int crop_w, uint8_t* out);
+/* Device frames in, device result out (d_out == NULL: the handle's buffer); asynchronous on the handle's stream. */
+int vq_resampler_run_u8_device(vq_resampler* r, const uint8_t* d_frames, int n, int h, int w, int filter,
+                               int out_h, int out_w, int crop_top, int crop_left, int crop_h, int crop_w, uint8_t* d_out);
+int vq_resampler_device_output(vq_resampler* r, void** d_ptr, int64_t* bytes);
+/* Output size and crop offsets of the CLIP image processor for an h x w frame
+ * (transformers image_transforms.py:295-299 get_resize_output_image_size + centre crop). */
+int vq_clip_processor_geometry(int h, int w, int size, int crop, int* resized_h, int* resized_w,
+                               int* crop_top, int* crop_left);
+/* OptimizedFrameExtractor._is_low_quality inputs (frame_extractor.py:301-316) for BGR uint8 frames:
+ * mean_brightness[i] = np.mean(frame_i); laplacian_var[i] = cv2.Laplacian(BGR2GRAY(frame_i), CV_64F).var().
+ * on_device != 0: `frames` is a device pointer.  (OpenCV is absent from the build container: this
+ * restates its published fixed-point grey conversion and 4-neighbour stencil; parity unpinned.) */
+int vq_frame_quality_u8(vq_resampler* r, const uint8_t* frames, int n, int h, int w, int on_device,
+                        double* mean_brightness, double* laplacian_var);
+
 #ifdef __cplusplus
 }
 #endif

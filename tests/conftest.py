@@ -45,3 +45,32 @@ def gpu_lib():
     from video_quierer_amd import _lib
     _lib.init(0)
     return _lib
+
+
+# ---- resize fixtures (tests/golden/resample_pil.npz; inputs are regenerated from the seed) ----
+RESAMPLE_SEED = 31337
+RESAMPLE_CASES = [            # (name, h, w, kind, mode)   kind: noise | smooth ; mode: stretch | clip
+    ("noise_97x131_stretch", 97, 131, "noise", "stretch"),
+    ("noise_300x400_clip", 300, 400, "noise", "clip"),
+    ("smooth_1080x1920_stretch", 1080, 1920, "smooth", "stretch"),
+    ("noise_1080x1920_clip", 1080, 1920, "noise", "clip"),
+    ("noise_719x405_clip", 719, 405, "noise", "clip"),
+    ("noise_224x224_stretch", 224, 224, "noise", "stretch"),
+    ("noise_100x80_stretch", 100, 80, "noise", "stretch"),          # upscale
+    ("noise_225x1000_clip", 225, 1000, "noise", "clip"),
+]
+
+
+def resample_input(h, w, kind, seed=RESAMPLE_SEED):
+    """Seeded test frames: uniform noise, or a smooth ramp + low-amplitude noise (what video frames look like)."""
+    rng = np.random.default_rng([seed, h, w])
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([yy * 255 // max(h - 1, 1), xx * 255 // max(w - 1, 1), (yy + xx) % 256], -1)
+    return np.clip(base + rng.integers(-6, 7, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+@pytest.fixture(scope="session")
+def golden_resample():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample_pil.npz"))

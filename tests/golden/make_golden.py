@@ -14,6 +14,9 @@ Produces
                              checksum of the frames/weights they came from.
   encoder_l14_336_seed1234.npz   (`make_golden.py l14`) 2 frames through the ViT-L/14@336 geometry.
   text_b32_seed1234.npz      (`make_golden.py text`) 16 synthetic prompts (token ids) through the text tower.
+  resample_pil.npz           (`make_golden.py resample`) Pillow's resize / transformers' CLIP image processor on
+                             seeded frames: two full outputs + SHA-256 of all eight (inputs are regenerated
+                             from the seed by resample_input()).
   knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
                              OptimizedHNSWIndex, random.seed(0)) over 1,000
                              seeded vectors: its levels, entry point and graph,
@@ -149,6 +152,31 @@ def capture_text():
                         embeddings=emb.numpy().astype(np.float32), weight_seed=WEIGHT_SEED)
 
 
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import RESAMPLE_CASES, RESAMPLE_SEED, resample_input    # noqa: E402  (shared with the tests)
+
+
+def capture_resample():
+    """Pillow (and transformers' CLIP image processor on top of it) on seeded frames: full outputs for the first two
+    cases, SHA-256 of the output bytes for all."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor()
+    mean, std = np.array(proc.image_mean, np.float32), np.array(proc.image_std, np.float32)
+    out = {"seed": RESAMPLE_SEED, "names": np.array([c[0] for c in RESAMPLE_CASES])}
+    for i, (name, h, w, kind, mode) in enumerate(RESAMPLE_CASES):
+        img = resample_input(h, w, kind)
+        if mode == "stretch":       # transforms.Resize((224,224)) on a PIL image = Image.resize(BILINEAR)
+            res = np.asarray(Image.fromarray(img).resize((224, 224), Image.BILINEAR))
+        else:                       # the processor's resize + centre crop, recovered from its normalised output
+            pv = proc(images=Image.fromarray(img), return_tensors="np")["pixel_values"][0]
+            res = np.rint((pv.transpose(1, 2, 0) * std + mean) * 255).astype(np.uint8)
+        out[f"sha256_{name}"] = hashlib.sha256(np.ascontiguousarray(res).tobytes()).hexdigest()
+        if i < 2:
+            out[f"out_{name}"] = res
+    np.savez_compressed(os.path.join(HERE, "resample_pil.npz"), **out)
+
+
 def capture_knn(queries):
     sys.path.insert(0, "/root/reference/src")
     from indexes.hnsw import OptimizedHNSWIndex        # the real reference
@@ -181,6 +209,9 @@ def capture_knn(queries):
 if __name__ == "__main__":
     if "l14" in sys.argv[1:]:
         capture_encoder_l14()
+        sys.exit(0)
+    if "resample" in sys.argv[1:]:
+        capture_resample()
         sys.exit(0)
     if "text" in sys.argv[1:]:
         capture_text()

@@ -582,3 +582,118 @@ def test_config2_batching_invariance(gpu_lib, b32_weights):
     assert np.array_equal(ea, eb)
     assert np.allclose(np.linalg.norm(ea, axis=1), 1.0, atol=1e-5)
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------ frame preprocessing in front of the encoder (§8f #3)
+@pytest.fixture(scope="module")
+def pre(gpu_lib):
+    from video_quierer_amd.preprocess import FramePreprocessor
+    p = FramePreprocessor()
+    yield p
+    p.close()
+
+
+def test_resample_matches_pillow_golden(pre, golden_resample):
+    """Bit-exact against Pillow / the CLIP image processor (captured in tests/golden/resample_pil.npz)."""
+    import hashlib
+    from conftest import RESAMPLE_CASES, resample_input
+    for i, (name, h, w, kind, mode) in enumerate(RESAMPLE_CASES):
+        img = resample_input(h, w, kind)
+        out = (pre.stretch(img) if mode == "stretch" else pre.clip_processor(img))[0]
+        assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+        assert hashlib.sha256(out.tobytes()).hexdigest() == str(golden_resample[f"sha256_{name}"]), name
+        if i < 2:
+            assert np.array_equal(out, golden_resample[f"out_{name}"])
+
+
+def test_resample_ragged_sizes_filters_crops_vs_oracle(pre):
+    from oracle import resample_oracle as ro
+    from video_quierer_amd.preprocess import BICUBIC, BILINEAR
+    rng = np.random.default_rng(8)
+    cases = [(37, 53, 224, 224), (300, 400, 201, 640), (2, 3, 7, 5), (1, 1, 4, 4), (500, 224, 224, 100), (64, 64, 64, 17),
+             (1080, 1920, 398, 224), (719, 405, 224, 397), (5, 5461, 31, 9), (480, 640, 640, 480)]
+    for (h, w, ow, oh) in cases:
+        n = 3 if h * w < 200000 else 1
+        frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        for filt in (BILINEAR, BICUBIC):
+            ref = np.stack([ro.resize_u8(f, ow, oh, filt) for f in frames])
+            assert np.array_equal(pre.resize(frames, oh, ow, filt), ref), (h, w, ow, oh, filt)
+            ct, cl = oh // 3, ow // 4                         # a window of the resized frame = the same pixels of the full result
+            ch, cw = max(1, oh // 2), max(1, ow // 2)
+            got = pre.resize(frames, oh, ow, filt, crop=(ct, cl, ch, cw))
+            assert np.array_equal(got, ref[:, ct:ct + ch, cl:cl + cw]), ("crop", h, w, ow, oh, filt)
+    # list of separately allocated frames == stacked frames; empty list
+    frames = [rng.integers(0, 256, (90, 160, 3), dtype=np.uint8) for _ in range(5)]
+    assert np.array_equal(pre.resize_list(frames, 224, 224), pre.resize(np.stack(frames), 224, 224))
+    assert pre.resize_list([], 224, 224).shape == (0, 224, 224, 3)
+    # bad arguments raise, as the reference's wrappers do
+    with pytest.raises(ValueError):
+        pre.resize(frames[0], 224, 224, filter=1)              # LANCZOS is not on the path
+    with pytest.raises(ValueError):
+        pre.resize(frames[0], 224, 224, crop=(200, 0, 100, 10))
+    with pytest.raises(TypeError):
+        pre.resize(frames[0].astype(np.float32), 224, 224)
+
+
+def test_resample_device_path_into_encoder(pre, encoder):
+    """Device-resident frames: resize on the GPU, hand the device buffer to the encoder — same embeddings as
+    encoding the Pillow-exact host result."""
+    import torch
+    from oracle import resample_oracle as ro
+    rng = np.random.default_rng(12)
+    frames = rng.integers(0, 256, (6, 270, 480, 3), dtype=np.uint8)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ptr = pre.resize_device(d.data_ptr(), 6, 270, 480, 224, 224)
+    pre.synchronize()
+    out = torch.empty((6, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    encoder.encode_device(ptr, 6, out.data_ptr(), swap_rb=True)
+    encoder.synchronize()
+    via_device = out.cpu().numpy()
+    host = np.stack([ro.stretch_to_square(f) for f in frames])
+    assert np.array_equal(via_device, encoder.encode(host, swap_rb=True))
+
+
+def test_feature_extractor_resizes_on_gpu(gpu_lib, b32_weights):
+    from oracle import resample_oracle as ro
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    rng = np.random.default_rng(13)
+    big = [rng.integers(0, 256, (360, 640, 3), dtype=np.uint8) for _ in range(5)]
+    tall = [rng.integers(0, 256, (300, 200, 3), dtype=np.uint8) for _ in range(2)]
+    native = list(synth_frames(3, seed=4))
+    mixed = [big[0], native[0], tall[0], big[1], native[1], big[2], tall[1], big[3], native[2], big[4]]
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=16, device_batch=16)
+    got = fx.extract_batch(mixed)
+    want = fx.extract_batch([f if f.shape[:2] == (224, 224) else ro.stretch_to_square(f) for f in mixed])
+    assert np.array_equal(got, want)                            # Resize((224,224)) moved to the GPU, bit for bit
+    emb = clip_vit_oracle.encode_frames(np.stack([ro.stretch_to_square(f) for f in mixed[:3]]), b32_weights)
+    assert min(float(np.dot(a, b)) for a, b in zip(got[:3], emb)) >= 1.0 - COS_TOL
+    from PIL import Image
+    pil = fx.extract_features(Image.fromarray(np.ascontiguousarray(big[0][..., ::-1])))    # RGB PIL == BGR ndarray
+    assert np.allclose(pil, got[0], atol=2e-3)
+    fx2 = FeatureExtractor(model_name="seed:1234", batch_size=16, device_batch=16, resize_mode="clip_processor")
+    got2 = fx2.extract_batch(big[:2])
+    want2 = fx2.extract_batch([ro.clip_processor_u8(f) for f in big[:2]])
+    assert np.array_equal(got2, want2) and not np.array_equal(got2, got[[0, 3]])
+    fx.thread_pool.shutdown(); fx2.thread_pool.shutdown()
+
+
+def test_frame_quality_vs_oracle(pre):
+    """np.mean(frame) exactly; Laplacian variance from exact integer sums vs numpy's float64 two-pass (1e-12);
+    the low-quality decision of reference frame_extractor.py:301-316 on dark / bright / flat / textured frames."""
+    from oracle import quality_oracle as q
+    rng = np.random.default_rng(14)
+    for (h, w) in [(224, 224), (37, 53), (1, 9), (9, 1), (1, 1), (480, 640)]:
+        frames = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+        frames[1] = (frames[1] // 16) + 100                      # low-contrast frame
+        mean, var = pre.quality(frames)
+        for i in range(3):
+            m, v = q.quality(frames[i])
+            assert mean[i] == m and abs(var[i] - v) <= 1e-12 * max(1.0, v), (h, w, i)
+    yy, xx = np.mgrid[0:240, 0:320]
+    smooth = np.stack([yy * 255 // 239, xx * 255 // 319, (yy + xx) // 3], -1).astype(np.uint8)
+    batch = np.stack([np.full((240, 320, 3), 5, np.uint8), np.full((240, 320, 3), 250, np.uint8), smooth,
+                      rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)])
+    low = pre.is_low_quality(batch)
+    assert low.tolist() == [q.is_low_quality(f) for f in batch] == [True, True, True, False]

@@ -92,3 +92,13 @@ def test_dropin_import_paths():
     for name in ("extract_features", "extract_batch", "extract_from_video_frames", "extract_batch_async",
                  "extract_text_features", "get_stats"):
         assert callable(getattr(FeatureExtractor, name))
+
+
+def test_clip_processor_geometry_matches_the_restatement():
+    """Host logic of the preprocessing boundary: output size / crop offsets for assorted frame sizes."""
+    from video_quierer_amd.preprocess import clip_processor_geometry
+    from oracle import resample_oracle
+    for (h, w) in [(1080, 1920), (300, 400), (224, 224), (225, 1000), (719, 405), (500, 224), (2160, 3840), (224, 225), (1000, 999)]:
+        assert clip_processor_geometry(h, w) == resample_oracle.clip_processor_geometry(h, w), (h, w)
+    with pytest.raises(ValueError):
+        clip_processor_geometry(0, 10)

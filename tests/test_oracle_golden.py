@@ -128,3 +128,47 @@ def test_text_oracle_matches_transformers():
     pad = np.full((g["input_ids"].shape[0], 77), 49407, dtype=np.int64)
     pad[:, :g["input_ids"].shape[1]] = g["input_ids"]
     assert np.array_equal(clip_vit_oracle.encode_token_ids(pad, W), emb)     # eos padding never reaches the pooled row
+
+
+# ------------------------------------------------------------------ resize in front of the encoder (§8f #3)
+def _resample_oracle_output(h, w, kind, mode):
+    from conftest import resample_input
+    from oracle import resample_oracle
+    img = resample_input(h, w, kind)
+    return resample_oracle.stretch_to_square(img) if mode == "stretch" else resample_oracle.clip_processor_u8(img)
+
+
+def test_resample_oracle_matches_pillow_golden(golden_resample):
+    from conftest import RESAMPLE_CASES
+    for i, (name, h, w, kind, mode) in enumerate(RESAMPLE_CASES):
+        out = _resample_oracle_output(h, w, kind, mode)
+        assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+        assert hashlib.sha256(out.tobytes()).hexdigest() == str(golden_resample[f"sha256_{name}"]), name
+        if i < 2:
+            assert np.array_equal(out, golden_resample[f"out_{name}"])
+
+
+def test_resample_oracle_matches_pillow_live():
+    """Where Pillow is importable (the build container), the restatement equals it on ragged sizes and both filters."""
+    Image = __import__("pytest").importorskip("PIL.Image")
+    from oracle import resample_oracle as ro
+    rng = np.random.default_rng(77)
+    for (h, w, ow, oh) in [(37, 53, 224, 224), (300, 400, 201, 640), (2, 3, 7, 5), (1, 1, 4, 4), (500, 224, 224, 100), (64, 64, 64, 17)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for filt, pil_filt in ((ro.BILINEAR, Image.BILINEAR), (ro.BICUBIC, Image.BICUBIC)):
+            assert np.array_equal(ro.resize_u8(img, ow, oh, filt), np.asarray(Image.fromarray(img).resize((ow, oh), pil_filt))), (h, w, ow, oh, filt)
+
+
+def test_quality_oracle_properties():
+    """Parity unpinned (OpenCV absent): pin the restatement's own invariants instead."""
+    from oracle import quality_oracle as q
+    flat = np.full((32, 48, 3), 120, np.uint8)
+    assert q.quality(flat) == (120.0, 0.0) and q.is_low_quality(flat)              # no texture -> "blurry"
+    assert q.is_low_quality(np.full((8, 8, 3), 10, np.uint8)) and q.is_low_quality(np.full((8, 8, 3), 250, np.uint8))
+    noise = np.random.default_rng(3).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    assert not q.is_low_quality(noise)
+    g = q.bgr_to_gray(np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8))
+    assert g.tolist() == [[255, 0, 29, 150, 76]]                                      # the familiar 0.114/0.587/0.299 greys
+    chk = np.indices((6, 6)).sum(0) % 2 * 255
+    L = q.laplacian_f64(chk.astype(np.uint8))
+    assert np.array_equal(np.abs(L), np.full((6, 6), 1020.0))                         # checkerboard: |L| = 4*255 everywhere (reflect-101 keeps parity)

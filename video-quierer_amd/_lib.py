@@ -11,7 +11,7 @@ import ctypes
 import os
 import subprocess
 import threading
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvq_amd.so")
@@ -78,6 +78,16 @@ SIGNATURES = {
     "vq_index_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
     "vq_index_profile_class_name": (c_char_p, [c_int]),
     "vq_index_last_search_stats": (c_int, [c_void_p, POINTER(c_int64)]),
+    "vq_resampler_create": (c_int, [POINTER(c_void_p)]),
+    "vq_resampler_destroy": (c_int, [c_void_p]),
+    "vq_resampler_set_stream": (c_int, [c_void_p, c_void_p]),
+    "vq_resampler_synchronize": (c_int, [c_void_p]),
+    "vq_resampler_run_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vq_resampler_run_u8_list": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vq_resampler_run_u8_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vq_resampler_device_output": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "vq_clip_processor_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "vq_frame_quality_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
 }
 
 _lock = threading.Lock()

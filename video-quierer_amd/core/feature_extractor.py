@@ -11,6 +11,9 @@ What differs from the reference, deliberately:
 * ``extract_text_features`` runs the CLIP text tower on the GPU; tokenisation needs the
   checkpoint's vocab.json / merges.txt (never fetched).  Seeded models have no tokenizer:
   use ``extract_text_features_from_ids``.
+* Frames that are not 224x224 are resized on the GPU, bit-identically to Pillow (preprocess.py);
+  ``resize_mode="clip_processor"`` selects the live path's short-edge-bicubic + centre-crop instead of the
+  reference class's stretch.
 * GEMMs run in bf16 with fp32 accumulation; embeddings agree with the fp32
   reference to cosine >= 1 - 1e-3 (tests/test_gpu_parity.py); ``compute_dtype="fp16"``
   switches the operands to fp16 (8x smaller error, same speed).
@@ -26,9 +29,10 @@ from typing import Any, Dict, List, Sequence, Union
 import numpy as np
 
 from video_quierer_amd.encoder import VitEncoder
+from video_quierer_amd.preprocess import BICUBIC, BILINEAR, FramePreprocessor, clip_processor_geometry
 from video_quierer_amd.weights import resolve_model
 
-try:  # PIL is only needed for PIL inputs / non-native sizes
+try:  # PIL is only needed to accept PIL inputs
     from PIL import Image
 except Exception:  # pragma: no cover
     Image = None
@@ -55,7 +59,10 @@ class FeatureExtractor:
 
     def __init__(self, model_name: str = "openai/clip-vit-base-patch32", device: str = "auto",
                  batch_size: int = 32, num_threads: int = 4, cache_model: bool = True,
-                 device_batch: int = 256, compute_dtype: str = "bf16"):
+                 device_batch: int = 256, compute_dtype: str = "bf16", resize_mode: str = "stretch"):
+        if resize_mode not in ("stretch", "clip_processor"):
+            raise ValueError("resize_mode must be 'stretch' (the reference's Resize((S,S))) or 'clip_processor'")
+        self.resize_mode = resize_mode
         self.model_name = model_name
         self.batch_size = batch_size
         self.num_threads = num_threads
@@ -73,6 +80,7 @@ class FeatureExtractor:
         self._text = None
         self._ordinal = ordinal
         self._load_model()
+        self._pre = FramePreprocessor(self.model.device)      # GPU resize for frames that are not S x S
         self.device = _DeviceName(f"cuda:{self.model.device}")
         logger.info(f"Using device: {self.device}")
         self.transform = self._preprocess_image      # reference attr: torchvision Compose (:54-61)
@@ -96,51 +104,73 @@ class FeatureExtractor:
             logger.error(f"Failed to load model: {e}")
             raise
 
-    # -- preprocessing (host side: only layout / size fix-ups; arithmetic is on the GPU) ----
-    def _preprocess_image(self, image: ImageLike):
-        """→ (uint8 [S,S,3], needs_channel_swap).  Reference :105-116: a 3-channel
-        ndarray is BGR (swapped on the GPU); a PIL image is RGB as-is; Resize((S,S))
-        is PIL bilinear and the identity at the native size."""
-        s = self.config.image_size
+    # -- preprocessing (host side: only layout fix-ups; resize and arithmetic are on the GPU) ----
+    def _as_u8(self, image: ImageLike):
+        """→ (uint8 [h,w,3], needs_channel_swap).  Reference :105-116: a 3-channel ndarray is BGR (swapped on the
+        GPU); a PIL image is RGB as-is."""
         if isinstance(image, np.ndarray):
             if image.ndim != 3 or image.shape[2] != 3:
                 raise ValueError(f"expected an HxWx3 uint8 array, got shape {image.shape}")
-            arr, swap = image, True
-            if arr.dtype != np.uint8:
-                raise TypeError(f"expected uint8 pixels, got {arr.dtype}")
-            if arr.shape[:2] != (s, s):
-                if Image is None:
-                    raise RuntimeError("PIL is required to resize frames")
-                # reference order: BGR2RGB, fromarray, Resize — resize is per channel, so it
-                # commutes with the channel swap the GPU applies afterwards
-                arr = np.asarray(Image.fromarray(arr).resize((s, s), Image.BILINEAR))
-            return arr, swap
+            if image.dtype != np.uint8:
+                raise TypeError(f"expected uint8 pixels, got {image.dtype}")
+            return image, True
         if Image is not None and isinstance(image, Image.Image):
             img = image.convert("RGB") if image.mode != "RGB" else image
-            if img.size != (s, s):
-                img = img.resize((s, s), Image.BILINEAR)
             return np.asarray(img, dtype=np.uint8), False
         raise TypeError(f"unsupported image type {type(image)!r}")
 
+    def _resize_group(self, arrs: List[np.ndarray]) -> np.ndarray:
+        """Frames of one non-native size → uint8 [n,S,S,3] on the GPU, bit-identical to Pillow: the reference's
+        ``Resize((S,S))`` (PIL bilinear, :55) or — ``resize_mode="clip_processor"`` — the live path's CLIP image
+        processor (short edge → S bicubic, centre crop; reference video_search_overhaul.py:129-135, :218-221).
+        Resizing is per channel, so it commutes with the channel swap the GPU applies afterwards."""
+        s = self.config.image_size
+        h, w = arrs[0].shape[:2]
+        if self.resize_mode == "clip_processor":
+            rh, rw, top, left = clip_processor_geometry(h, w, s, s)
+            return self._pre.resize_list(arrs, rh, rw, BICUBIC, crop=(top, left, s, s))
+        return self._pre.resize_list(arrs, s, s, BILINEAR)
+
+    def _preprocess_image(self, image: ImageLike):
+        """→ (uint8 [S,S,3], needs_channel_swap)."""
+        s = self.config.image_size
+        arr, swap = self._as_u8(image)
+        if arr.shape[:2] != (s, s):
+            arr = self._resize_group([arr])[0]
+        return arr, swap
+
     def _preprocess_batch(self, images: Sequence[ImageLike], into: np.ndarray = None):
         """Reference :118-129 — here: one contiguous uint8 batch + a swap flag.  Like the reference, the
-        per-image work (here a 150 KB copy, plus a PIL resize for odd sizes) fans out over the thread pool
-        when there are more than 4 images (:123-124); numpy releases the GIL for the copies."""
+        per-image work (a 150 KB copy) fans out over the thread pool when there are more than 4 images
+        (:123-124; numpy releases the GIL for the copies).  Frames that are not S x S are grouped by size and
+        resized on the GPU."""
         s = self.config.image_size
         n = len(images)
         batch = np.empty((n, s, s, 3), dtype=np.uint8) if into is None else into[:n]     # `into`: pinned staging slot
         swaps = [True] * n
+        odd: List[Any] = [None] * n
 
         def fill(lo, hi):
             for i in range(lo, hi):
-                arr, swaps[i] = self._preprocess_image(images[i])
-                batch[i] = arr
+                arr, swaps[i] = self._as_u8(images[i])
+                if arr.shape[:2] == (s, s):
+                    batch[i] = arr
+                else:
+                    odd[i] = arr
 
         if self.num_threads > 1 and n > 4:
             step = -(-n // self.num_threads)
             list(self.thread_pool.map(lambda lo: fill(lo, min(n, lo + step)), range(0, n, step)))
         else:
             fill(0, n)
+        groups: Dict[Any, List[int]] = {}
+        for i, arr in enumerate(odd):
+            if arr is not None:
+                groups.setdefault(arr.shape[:2], []).append(i)
+        for idxs in groups.values():
+            out = self._resize_group([odd[i] for i in idxs])
+            for j, i in enumerate(idxs):
+                batch[i] = out[j]
         if all(swaps):
             return batch, True
         for i, sw in enumerate(swaps):          # mixed list: bring ndarray frames to RGB on the host

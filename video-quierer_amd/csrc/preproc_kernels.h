@@ -1,0 +1,218 @@
+// Frame preprocessing upstream of the encoder: Pillow's separable 8-bit resample
+// (src/libImaging/Resample.c) as two integer passes, and the frame-quality statistics of
+// reference src/core/frame_extractor.py:301-316.  Byte/integer work, HBM-bound: a source frame is read once
+// (staged through LDS row by row), the uint8 intermediate is the only extra traffic.
+#pragma once
+#include "vq_common.h"
+#ifndef RS_MUL
+#define RS_MUL(a, b) __mul24((a), (b))
+#endif
+
+namespace vq {
+
+constexpr int RS_PRECISION_BITS = 32 - 8 - 2;       // Resample.c PRECISION_BITS: 22-bit fixed-point weights
+constexpr int RS_THREADS = 256;
+
+__device__ __forceinline__ uint8_t rs_clip8(int v) {
+    v >>= RS_PRECISION_BITS;                          // arithmetic shift, as clip8() does
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// Horizontal pass (ImagingResampleHorizontal_8bpc, 3 bands).
+// A workgroup (4 waves) owns RSH_ROWS = 64 source rows x one segment of `oc` output columns.  It stages the
+// source bytes those columns touch into LDS, one dword-aligned row per LDS row (row pitch an odd number of
+// dwords), then LANE = ROW: a wave takes output columns of the segment in turn, so the tap window and the
+// weights are wave-uniform (scalar loads) and every lane streams consecutive dwords of its own row,
+// bank-conflict free.  Four taps = 12 bytes = three dwords, realigned with v_alignbyte by the row's byte
+// offset; each byte costs one extract and one multiply-add.  Results go through an LDS tile so the global
+// stores are row-contiguous.
+//   src  [n][h][w][3]; the pass covers source rows [row_first, row_first + rows_needed) of every frame
+//   tmp  [n][rows_needed][out_cols][3] for output columns [col_first, col_first + out_cols)
+//   kk rows are `ksize` ints, ksize a multiple of 4, zero beyond the tap count
+constexpr int RSH_ROWS = 64;
+
+template <bool DWORD_STORE>
+__global__ __launch_bounds__(RS_THREADS)
+void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
+                       const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                       int h, int w, int row_first, int rows_needed, int col_first, int out_cols,
+                       int oc, int pitch_dw, int tile_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    uint8_t* tile = (uint8_t*)(lds32 + RSH_ROWS * pitch_dw);        // [64][tile_pitch] bytes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int img = blockIdx.z, r0 = blockIdx.y * RSH_ROWS;
+    const int xo0 = blockIdx.x * oc, ncol = min(oc, out_cols - xo0);
+    const int xx0 = col_first + xo0;
+    const int sx0 = bounds[2 * xx0];                                 // first source pixel the segment touches
+    const int sx1 = bounds[2 * (xx0 + ncol - 1)] + bounds[2 * (xx0 + ncol - 1) + 1];
+    const int span_bytes = (sx1 - sx0) * 3;
+    const size_t pitch = (size_t)w * 3;
+    const uint8_t* seg0 = src + ((size_t)img * h + row_first) * pitch + (size_t)sx0 * 3;
+
+    // ---- stage: wave w copies rows w, w+4, ...; a row starts at the aligned dword that holds its first byte
+    // (an aligned dword that contains a valid byte never leaves that byte's page, so the up-to-3 bytes read
+    // before / after the span are harmless).  Loads are issued 4 rows x 4 dwords-per-lane at a time so that
+    // 16 of them are in flight per lane instead of one. ----
+    constexpr int RBAT = 4, JBAT = 4;
+    for (int rb = wave; rb < RSH_ROWS; rb += 4 * RBAT) {
+        const uint8_t* ga[RBAT];
+        int nd[RBAT];
+#pragma unroll
+        for (int b = 0; b < RBAT; ++b) {
+            const int row = min(r0 + rb + 4 * b, rows_needed - 1);   // rows past the end repeat the last one, never stored
+            const uint8_t* g = seg0 + (size_t)row * pitch;
+            const int a = (int)((uintptr_t)g & 3);
+            ga[b] = g - a;
+            nd[b] = (a + span_bytes + 3) >> 2;
+        }
+        for (int j0 = lane; j0 < pitch_dw; j0 += 64 * JBAT) {
+            uint32_t v[RBAT][JBAT];
+#pragma unroll
+            for (int b = 0; b < RBAT; ++b)
+#pragma unroll
+                for (int jj = 0; jj < JBAT; ++jj) {
+                    const int j = j0 + 64 * jj;
+                    v[b][jj] = j < nd[b] ? *(const uint32_t*)(ga[b] + 4 * (size_t)j) : 0u;
+                }
+#pragma unroll
+            for (int b = 0; b < RBAT; ++b)
+#pragma unroll
+                for (int jj = 0; jj < JBAT; ++jj) {
+                    const int j = j0 + 64 * jj;
+                    if (j < nd[b]) lds32[(rb + 4 * b) * pitch_dw + j] = v[b][jj];
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: lane = row ----
+    const int my_row = min(r0 + lane, rows_needed - 1);
+    const int a = (int)((uintptr_t)(seg0 + (size_t)my_row * pitch) & 3);
+    const uint32_t* rowp = lds32 + lane * pitch_dw;
+    for (int c = wave; c < ncol; c += 4) {
+        const int xx = xx0 + c;
+        const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const int* k = kk + (size_t)xx * ksize;
+        const int off = a + (xmin - sx0) * 3;
+        int di = off >> 2;
+        const int sh = off & 3;
+        int s0 = 1 << (RS_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        uint32_t d0 = rowp[di];
+        const int nchunk = (cnt + 3) >> 2;
+        for (int q = 0; q < nchunk; ++q) {
+            const uint32_t d1 = rowp[di + 1], d2 = rowp[di + 2], d3 = rowp[di + 3];
+            const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            const uint32_t e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            const int k0 = k[4 * q], k1 = k[4 * q + 1], k2 = k[4 * q + 2], k3 = k[4 * q + 3];
+            // weights are 23-bit signed, pixels 8-bit: v_mad_i32_i24 (full rate) instead of a 32-bit multiply
+            s0 += RS_MUL((int)(e0 & 255), k0);         s1 += RS_MUL((int)((e0 >> 8) & 255), k0);  s2 += RS_MUL((int)((e0 >> 16) & 255), k0);
+            s0 += RS_MUL((int)(e0 >> 24), k1);         s1 += RS_MUL((int)(e1 & 255), k1);         s2 += RS_MUL((int)((e1 >> 8) & 255), k1);
+            s0 += RS_MUL((int)((e1 >> 16) & 255), k2); s1 += RS_MUL((int)(e1 >> 24), k2);         s2 += RS_MUL((int)(e2 & 255), k2);
+            s0 += RS_MUL((int)((e2 >> 8) & 255), k3);  s1 += RS_MUL((int)((e2 >> 16) & 255), k3); s2 += RS_MUL((int)(e2 >> 24), k3);
+            d0 = d3;
+            di += 3;
+        }
+        uint8_t* o = tile + lane * tile_pitch + c * 3;
+        o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+    }
+    __syncthreads();
+
+    // ---- store the 64 x ncol tile, row-contiguous ----
+    const int rows = min(RSH_ROWS, rows_needed - r0);
+    uint8_t* out0 = tmp + (((size_t)img * rows_needed + r0) * out_cols + xo0) * 3;
+    const size_t out_pitch = (size_t)out_cols * 3;
+    if constexpr (DWORD_STORE) {
+        const int nd = (ncol * 3) >> 2;                              // <= 24 dwords: half a wave per row
+        const int j = lane & 31;
+        for (int r = wave * 2 + (lane >> 5); r < rows; r += 8)
+            if (j < nd) *(uint32_t*)(out0 + r * out_pitch + 4 * j) = *(const uint32_t*)(tile + r * tile_pitch + 4 * j);
+    } else {
+        const int nb = ncol * 3;
+        for (int r = wave; r < rows; r += 4)
+            for (int j = lane; j < nb; j += 64) out0[r * out_pitch + j] = tile[r * tile_pitch + j];
+    }
+}
+
+// Vertical pass (ImagingResampleVertical_8bpc): the weights of an output row are workgroup-uniform.  A thread
+// produces VEC consecutive bytes of one output row (VEC = 4 when rows are dword-aligned, else 1).
+// tmp [n][rows_in][row_bytes], dst [n][out_rows][row_bytes] for output rows [row_first, row_first + out_rows);
+// `row_shift` is the source row that tmp row 0 corresponds to.
+template <int VEC>
+__global__ __launch_bounds__(RS_THREADS)
+void resample_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ dst,
+                       const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                       int rows_in, int row_bytes, int row_first, int out_rows, int row_shift) {
+    const int j = (blockIdx.x * RS_THREADS + threadIdx.x) * VEC;
+    const int yo = blockIdx.y, img = blockIdx.z;
+    if (j >= row_bytes) return;
+    const int yy = row_first + yo;
+    const int ymin = bounds[2 * yy] - row_shift, cnt = bounds[2 * yy + 1];
+    const int* k = kk + (size_t)yy * ksize;
+    const uint8_t* p = tmp + ((size_t)img * rows_in + ymin) * row_bytes + j;
+    uint8_t* o = dst + ((size_t)img * out_rows + yo) * row_bytes + j;
+    if constexpr (VEC == 4) {
+        int s0 = 1 << (RS_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+        for (int t = 0; t < cnt; ++t) {
+            const uint32_t v = *(const uint32_t*)(p + (size_t)t * row_bytes);
+            const int c = k[t];
+            s0 += __mul24((int)(v & 255), c); s1 += __mul24((int)((v >> 8) & 255), c); s2 += __mul24((int)((v >> 16) & 255), c); s3 += __mul24((int)(v >> 24), c);
+        }
+        // Each clipped byte goes through an opaque register move before packing: ROCm 7.2's backend otherwise
+        // folds clamp(x >> 22) pairs into v_ashr_pk_u8_i32, whose upper destination half it does not clear
+        // (bytes 2-3 of the packed dword came out as stale register contents on gfx950).
+        uint32_t b0 = rs_clip8(s0), b1 = rs_clip8(s1), b2 = rs_clip8(s2), b3 = rs_clip8(s3);
+        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        *(uint32_t*)o = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    } else {
+        int s = 1 << (RS_PRECISION_BITS - 1);
+        for (int t = 0; t < cnt; ++t) s += __mul24((int)p[(size_t)t * row_bytes], k[t]);
+        *o = rs_clip8(s);
+    }
+}
+
+// ---- frame quality (reference frame_extractor.py:301-316) ------------------------------------------------
+// per frame: sum of all bytes (np.mean(frame)), and over the grey image g = BGR2GRAY(frame) the sums of
+// L and L^2 where L = cv2.Laplacian(g, CV_64F) (aperture 1: the 4-neighbour stencil, BORDER_REFLECT_101).
+// Grey conversion: OpenCV 4.x fixed point, (B*3735 + G*19235 + R*9798 + 2^14) >> 15.
+__device__ __forceinline__ int gray_bgr(const uint8_t* p) {
+    return (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
+}
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    if (i < 0) return -i;
+    if (i >= n) return 2 * n - 2 - i;
+    return i;
+}
+
+// acc [n][3] int64: {sum bytes, sum L, sum L^2}; zeroed by the caller.  One thread per pixel.
+__global__ __launch_bounds__(RS_THREADS)
+void frame_quality_kernel(const uint8_t* __restrict__ frames, long long* __restrict__ acc, int h, int w) {
+    const int img = blockIdx.y;
+    const uint8_t* f = frames + (size_t)img * h * w * 3;
+    long long sb = 0, sl = 0, sl2 = 0;
+    const int total = h * w;
+    for (int idx = blockIdx.x * RS_THREADS + threadIdx.x; idx < total; idx += gridDim.x * RS_THREADS) {
+        const int y = idx / w, x = idx - y * w;
+        const uint8_t* p = f + (size_t)idx * 3;
+        sb += p[0] + p[1] + p[2];
+        const int yu = reflect101(y - 1, h), yd = reflect101(y + 1, h);
+        const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+        const int lap = gray_bgr(f + ((size_t)yu * w + x) * 3) + gray_bgr(f + ((size_t)yd * w + x) * 3) +
+                        gray_bgr(f + ((size_t)y * w + xl) * 3) + gray_bgr(f + ((size_t)y * w + xr) * 3) - 4 * gray_bgr(p);
+        sl += lap; sl2 += (long long)lap * lap;
+    }
+    // wave reduction, then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sb += __shfl_down(sb, off); sl += __shfl_down(sl, off); sl2 += __shfl_down(sl2, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&acc[img * 3 + 0], (unsigned long long)sb);
+        atomicAdd((unsigned long long*)&acc[img * 3 + 1], (unsigned long long)sl);
+        atomicAdd((unsigned long long*)&acc[img * 3 + 2], (unsigned long long)sl2);
+    }
+}
+
+}  // namespace vq
