@@ -22,7 +22,7 @@ __device__ __forceinline__ uint8_t rs_clip8(int v) {
 // A workgroup (4 waves) owns RSH_ROWS = 64 source rows x one segment of `oc` output columns.  It stages the
 // source bytes those columns touch into LDS, one dword-aligned row per LDS row (row pitch an odd number of
 // dwords), then LANE = ROW: a wave takes output columns of the segment in turn, so the tap window and the
-// weights are wave-uniform (scalar loads) and every lane streams consecutive dwords of its own row,
+// weights are wave-uniform (the weights sit in LDS, read as broadcasts) and every lane streams consecutive dwords of its own row,
 // bank-conflict free.  Four taps = 12 bytes = three dwords, realigned with v_alignbyte by the row's byte
 // offset; each byte costs one extract and one multiply-add.  Results go through an LDS tile so the global
 // stores are row-contiguous.
@@ -30,6 +30,8 @@ __device__ __forceinline__ uint8_t rs_clip8(int v) {
 //   tmp  [n][rows_needed][out_cols][3] for output columns [col_first, col_first + out_cols)
 //   kk rows are `ksize` ints, ksize a multiple of 4, zero beyond the tap count
 constexpr int RSH_ROWS = 64;
+typedef __attribute__((address_space(3))) void rs_lds_t;
+typedef const __attribute__((address_space(1))) void rs_gbl_t;
 
 template <bool DWORD_STORE>
 __global__ __launch_bounds__(RS_THREADS)
@@ -39,6 +41,7 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
                        int oc, int pitch_dw, int tile_pitch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
     uint8_t* tile = (uint8_t*)(lds32 + RSH_ROWS * pitch_dw);        // [64][tile_pitch] bytes
+    int* kl = (int*)(tile + RSH_ROWS * tile_pitch);                  // [oc][ksize] weights of this segment's columns
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int img = blockIdx.z, r0 = blockIdx.y * RSH_ROWS;
@@ -50,40 +53,23 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
     const size_t pitch = (size_t)w * 3;
     const uint8_t* seg0 = src + ((size_t)img * h + row_first) * pitch + (size_t)sx0 * 3;
 
-    // ---- stage: wave w copies rows w, w+4, ...; a row starts at the aligned dword that holds its first byte
-    // (an aligned dword that contains a valid byte never leaves that byte's page, so the up-to-3 bytes read
-    // before / after the span are harmless).  Loads are issued 4 rows x 4 dwords-per-lane at a time so that
-    // 16 of them are in flight per lane instead of one. ----
-    constexpr int RBAT = 4, JBAT = 4;
-    for (int rb = wave; rb < RSH_ROWS; rb += 4 * RBAT) {
-        const uint8_t* ga[RBAT];
-        int nd[RBAT];
-#pragma unroll
-        for (int b = 0; b < RBAT; ++b) {
-            const int row = min(r0 + rb + 4 * b, rows_needed - 1);   // rows past the end repeat the last one, never stored
-            const uint8_t* g = seg0 + (size_t)row * pitch;
-            const int a = (int)((uintptr_t)g & 3);
-            ga[b] = g - a;
-            nd[b] = (a + span_bytes + 3) >> 2;
-        }
-        for (int j0 = lane; j0 < pitch_dw; j0 += 64 * JBAT) {
-            uint32_t v[RBAT][JBAT];
-#pragma unroll
-            for (int b = 0; b < RBAT; ++b)
-#pragma unroll
-                for (int jj = 0; jj < JBAT; ++jj) {
-                    const int j = j0 + 64 * jj;
-                    v[b][jj] = j < nd[b] ? *(const uint32_t*)(ga[b] + 4 * (size_t)j) : 0u;
-                }
-#pragma unroll
-            for (int b = 0; b < RBAT; ++b)
-#pragma unroll
-                for (int jj = 0; jj < JBAT; ++jj) {
-                    const int j = j0 + 64 * jj;
-                    if (j < nd[b]) lds32[(rb + 4 * b) * pitch_dw + j] = v[b][jj];
-                }
-        }
+    // ---- stage: wave w copies rows w, w+4, ... with LDS-DMA dword loads (64 lanes -> 64 consecutive LDS dwords,
+    // no VGPR round trip).  A row starts at the aligned dword that holds its first byte; an aligned dword that
+    // contains a valid byte never leaves that byte's page, so the up-to-3 bytes read before / after the span
+    // are harmless. ----
+    for (int rr = wave; rr < RSH_ROWS; rr += 4) {
+        const int row = min(r0 + rr, rows_needed - 1);               // rows past the end repeat the last one, never stored
+        const uint8_t* g = seg0 + (size_t)row * pitch;
+        const int a = (int)((uintptr_t)g & 3);
+        const uint8_t* ga = g - a;
+        const int nd = (a + span_bytes + 3) >> 2;
+        for (int j0 = 0; j0 < nd; j0 += 64)
+            if (j0 + lane < nd)
+                __builtin_amdgcn_global_load_lds((rs_gbl_t*)(ga + 4 * (size_t)(j0 + lane)),
+                                                 (rs_lds_t*)(lds32 + rr * pitch_dw + j0), 4, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = threadIdx.x; i < ncol * ksize; i += RS_THREADS) kl[i] = kk[(size_t)xx0 * ksize + i];
     __syncthreads();
 
     // ---- compute: lane = row ----
@@ -93,7 +79,7 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
     for (int c = wave; c < ncol; c += 4) {
         const int xx = xx0 + c;
         const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
-        const int* k = kk + (size_t)xx * ksize;
+        const int4* k = (const int4*)(kl + c * ksize);              // wave-uniform address: an LDS broadcast read
         const int off = a + (xmin - sx0) * 3;
         int di = off >> 2;
         const int sh = off & 3;
@@ -105,7 +91,8 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
             const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
             const uint32_t e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
             const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            const int k0 = k[4 * q], k1 = k[4 * q + 1], k2 = k[4 * q + 2], k3 = k[4 * q + 3];
+            const int4 kq = k[q];
+            const int k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;
             // weights are 23-bit signed, pixels 8-bit: v_mad_i32_i24 (full rate) instead of a 32-bit multiply
             s0 += RS_MUL((int)(e0 & 255), k0);         s1 += RS_MUL((int)((e0 >> 8) & 255), k0);  s2 += RS_MUL((int)((e0 >> 16) & 255), k0);
             s0 += RS_MUL((int)(e0 >> 24), k1);         s1 += RS_MUL((int)(e1 & 255), k1);         s2 += RS_MUL((int)((e1 >> 8) & 255), k1);

@@ -153,7 +153,7 @@ int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int f
         pitch_dw = (span_max(oc) * 3 + 24 + 3) / 4 | 1;       // + realignment and zero-weight over-read slack; odd
         tile_pitch = (oc * 3 + 3) / 4 * 4;
         if (((tile_pitch / 4) & 1) == 0) tile_pitch += 4;
-        lds = (size_t)RSH_ROWS * pitch_dw * 4 + (size_t)RSH_ROWS * tile_pitch;
+        lds = (size_t)RSH_ROWS * pitch_dw * 4 + (size_t)RSH_ROWS * tile_pitch + (size_t)oc * r->ch.ksize * 4;
         if (lds <= 48 * 1024 || oc == 1) break;
         oc = oc > 4 ? oc - 4 : oc - 1;
     }
