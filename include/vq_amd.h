@@ -94,6 +94,15 @@ int vq_encoder_encode_u8_device(vq_encoder* enc, const void* d_frames, int n, in
  * blocks only its own thread) another thread may fill slot 1-s.  n <= max_batch. */
 int vq_encoder_staging(vq_encoder* enc, int slot, uint8_t** host_ptr, size_t* bytes);
 int vq_encoder_encode_staged(vq_encoder* enc, int slot, int n, int swap_rb, float* out);
+/* Pipelined ingest of host frames (what extract_from_video_frames, feature_extractor.py:179-209, loops over):
+ *   vq_encoder_stage_frames   gathers n separately allocated S x S x 3 uint8 frames (a Python list of ndarray
+ *                             frames) into pinned slot 0/1 on up to n_threads host threads;
+ *   vq_encoder_submit_staged  enqueues upload (copy stream) -> forward -> download for that slot and returns;
+ *   vq_encoder_wait_staged    blocks until the slot's batch is done and copies out [n][proj_dim] fp32.
+ * With two slots the upload and the host gather of batch i+1 overlap the forward pass of batch i. */
+int vq_encoder_stage_frames(vq_encoder* enc, int slot, const uint8_t* const* frames, int n, int n_threads);
+int vq_encoder_submit_staged(vq_encoder* enc, int slot, int n, int swap_rb);
+int vq_encoder_wait_staged(vq_encoder* enc, int slot, float* out);
 int vq_encoder_synchronize(vq_encoder* enc);
 /* Run this handle's kernels on a caller-owned HIP stream (e.g. torch's current
  * stream, so RCCL collectives issued by torch order after the encode without a

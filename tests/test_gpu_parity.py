@@ -697,3 +697,34 @@ def test_frame_quality_vs_oracle(pre):
                       rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)])
     low = pre.is_low_quality(batch)
     assert low.tolist() == [q.is_low_quality(f) for f in batch] == [True, True, True, False]
+
+
+def test_pipelined_ingest_matches_single_pass(gpu_lib):
+    """stage_frames / submit_staged / wait_staged (two slots, two handles) return exactly what a plain encode of the
+    same frames returns, in order, for full, ragged and mixed-size batches; misuse raises."""
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=16)      # 16-frame passes -> many passes
+    frames = list(synth_frames(150, seed=31))
+    fds = [{"frame": f, "frame_number": i} for i, f in enumerate(frames)]
+    out = fx.extract_from_video_frames(fds)                                           # 10 passes: both ingest handles
+    assert [o["frame_number"] for o in out] == list(range(150))
+    ref = fx.model.encode(np.stack(frames[:150]))
+    got = np.stack([o["features"] for o in out])
+    assert np.abs(got - ref).max() <= 2e-6            # different tile shapes (160- vs 256-row GEMM tiles): fp32 summation order only
+    few = fx.extract_from_video_frames(fds[:20])                                      # 2 passes: the single handle
+    assert np.array_equal(np.stack([o["features"] for o in few]), ref[:20])
+    odd = [dict(fd) for fd in fds[:40]]
+    odd[3]["frame"] = np.ascontiguousarray(np.repeat(np.repeat(frames[3], 2, 0), 2, 1))   # 448x448: resized on the GPU
+    mixed = fx.extract_from_video_frames(odd)
+    assert np.abs(np.stack([o["features"] for i, o in enumerate(mixed) if i != 3]) - np.delete(ref[:40], 3, 0)).max() <= 2e-6
+    m = fx.model
+    m.stage_frames(0, frames[:4])
+    m.submit_staged(0, 4)
+    with pytest.raises(ValueError):
+        m.submit_staged(0, 4)                          # slot busy
+    with pytest.raises(ValueError):
+        m.stage_frames(0, frames[:4])                  # would overwrite a batch in flight
+    assert np.array_equal(m.wait_staged(0, 4), ref[:4])
+    with pytest.raises(ValueError):
+        m.wait_staged(0, 4)                            # nothing in flight
+    fx.thread_pool.shutdown()

@@ -78,6 +78,9 @@ SIGNATURES = {
     "vq_index_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
     "vq_index_profile_class_name": (c_char_p, [c_int]),
     "vq_index_last_search_stats": (c_int, [c_void_p, POINTER(c_int64)]),
+    "vq_encoder_stage_frames": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_int, c_int]),
+    "vq_encoder_submit_staged": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "vq_encoder_wait_staged": (c_int, [c_void_p, c_int, POINTER(c_float)]),
     "vq_resampler_create": (c_int, [POINTER(c_void_p)]),
     "vq_resampler_destroy": (c_int, [c_void_p]),
     "vq_resampler_set_stream": (c_int, [c_void_p, c_void_p]),

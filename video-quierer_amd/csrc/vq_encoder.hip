@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace vq {
@@ -61,6 +62,13 @@ struct vq_encoder {
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
     uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned staging slots (lazy)
     float* h_out_stage = nullptr;               // pinned result buffer
+    // pipelined ingest (vq_encoder_submit_staged / wait_staged): per-slot device frames + pinned results, a copy
+    // stream for the uploads, events ordering upload -> forward -> download per slot
+    uint8_t* d_slot_frames[2] = {nullptr, nullptr};
+    float* h_slot_out[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_fwd[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int slot_n[2] = {0, 0};                     // frames in flight per slot (0 = idle)
     int run_layers = -1;
     int last_n = 0;
     bool is_text = false;       // CLIP text tower (vq_text_encoder_*): token embedding, causal attention, EOS pooling
@@ -556,6 +564,14 @@ int vq_encoder_destroy(vq_encoder* e) {
     if (e->arena.base) (void)hipFree(e->arena.base);
     for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
     if (e->h_out_stage) (void)hipHostFree(e->h_out_stage);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    for (int i = 0; i < 2; ++i) {
+        if (e->d_slot_frames[i]) (void)hipFree(e->d_slot_frames[i]);
+        if (e->h_slot_out[i]) (void)hipHostFree(e->h_slot_out[i]);
+        if (e->ev_h2d[i]) (void)hipEventDestroy(e->ev_h2d[i]);
+        if (e->ev_fwd[i]) (void)hipEventDestroy(e->ev_fwd[i]);
+        if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
+    }
     delete e;
     return 0;
 }
@@ -616,6 +632,81 @@ int vq_encoder_encode_staged(vq_encoder* e, int slot, int n, int swap_rb, float*
     VQ_HIP(hipMemcpyAsync(e->h_out_stage, e->d_out, (size_t)n * e->cfg.proj_dim * 4, hipMemcpyDeviceToHost, e->stream));
     VQ_HIP(hipStreamSynchronize(e->stream));
     memcpy(out, e->h_out_stage, (size_t)n * e->cfg.proj_dim * 4);
+    return 0;
+}
+
+// Host gather: n separately allocated frames -> pinned staging slot, on up to n_threads threads.
+int vq_encoder_stage_frames(vq_encoder* e, int slot, const uint8_t* const* frames, int n, int n_threads) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && !e->is_text && frames && (slot == 0 || slot == 1), "vq_encoder_stage_frames: bad argument");
+    VQ_CHECK(n > 0 && n <= e->max_batch, "vq_encoder_stage_frames: n=%d outside (0, max_batch=%d]", n, e->max_batch);
+    for (int i = 0; i < n; ++i) VQ_CHECK(frames[i], "vq_encoder_stage_frames: frame %d is null", i);
+    uint8_t* dst = nullptr;
+    size_t bytes = 0;
+    VQ_TRY(vq_encoder_staging(e, slot, &dst, &bytes));
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        VQ_CHECK(e->slot_n[slot] == 0, "vq_encoder_stage_frames: slot %d still has a submitted batch (wait for it first)", slot);
+    }
+    const size_t fbytes = (size_t)e->cfg.image_size * e->cfg.image_size * 3;
+    const int nt = std::max(1, std::min(std::min(n_threads, 16), n / 8));
+    auto work = [&](int t) {
+        for (int i = t; i < n; i += nt) memcpy(dst + (size_t)i * fbytes, frames[i], fbytes);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    return 0;
+}
+
+// Asynchronous: upload slot -> forward -> download, ordered by events; the upload runs on the handle's copy
+// stream so that it overlaps the forward pass of the other slot.
+int vq_encoder_submit_staged(vq_encoder* e, int slot, int n, int swap_rb) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && !e->is_text && (slot == 0 || slot == 1) && e->h_stage[slot], "vq_encoder_submit_staged: bad argument / slot not staged");
+    VQ_CHECK(n > 0 && n <= e->max_batch, "vq_encoder_submit_staged: n=%d outside (0, max_batch=%d]", n, e->max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    VQ_CHECK(e->slot_n[slot] == 0, "vq_encoder_submit_staged: slot %d already has a batch in flight", slot);
+    const size_t fbytes = (size_t)e->cfg.image_size * e->cfg.image_size * 3;
+    if (!e->copy_stream) VQ_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->d_slot_frames[slot]) {
+        VQ_HIP(hipMalloc((void**)&e->d_slot_frames[slot], (size_t)e->max_batch * fbytes));
+        VQ_HIP(hipHostMalloc((void**)&e->h_slot_out[slot], (size_t)e->max_batch * e->cfg.proj_dim * 4));
+        VQ_HIP(hipEventCreateWithFlags(&e->ev_h2d[slot], hipEventDisableTiming));
+        VQ_HIP(hipEventCreateWithFlags(&e->ev_fwd[slot], hipEventDisableTiming));
+        VQ_HIP(hipEventCreateWithFlags(&e->ev_done[slot], hipEventDisableTiming));
+    } else {
+        VQ_HIP(hipStreamWaitEvent(e->copy_stream, e->ev_fwd[slot], 0));    // the slot's previous forward has consumed its frames
+    }
+    VQ_HIP(hipMemcpyAsync(e->d_slot_frames[slot], e->h_stage[slot], n * fbytes, hipMemcpyHostToDevice, e->copy_stream));
+    VQ_HIP(hipEventRecord(e->ev_h2d[slot], e->copy_stream));
+    VQ_HIP(hipStreamWaitEvent(e->stream, e->ev_h2d[slot], 0));
+    VQ_TRY(forward(e, e->d_slot_frames[slot], n, swap_rb, e->d_out, nullptr));
+    VQ_HIP(hipEventRecord(e->ev_fwd[slot], e->stream));
+    VQ_HIP(hipMemcpyAsync(e->h_slot_out[slot], e->d_out, (size_t)n * e->cfg.proj_dim * 4, hipMemcpyDeviceToHost, e->stream));
+    VQ_HIP(hipEventRecord(e->ev_done[slot], e->stream));
+    e->slot_n[slot] = n;
+    return 0;
+}
+
+int vq_encoder_wait_staged(vq_encoder* e, int slot, float* out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(e && out && (slot == 0 || slot == 1), "vq_encoder_wait_staged: bad argument");
+    int n;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        n = e->slot_n[slot];
+        VQ_CHECK(n > 0, "vq_encoder_wait_staged: slot %d has no batch in flight", slot);
+    }
+    VQ_HIP(hipEventSynchronize(e->ev_done[slot]));
+    memcpy(out, e->h_slot_out[slot], (size_t)n * e->cfg.proj_dim * 4);
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->slot_n[slot] = 0;
     return 0;
 }
 

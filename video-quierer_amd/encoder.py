@@ -67,6 +67,29 @@ class VitEncoder:
         _lib.check(_lib.load().vq_encoder_encode_staged(self._h, int(slot), int(n), int(bool(swap_rb)), _lib.fptr(out)))
         return out
 
+    # -- pipelined ingest of host frames ------------------------------------------
+    def stage_frames(self, slot: int, frames, n_threads: int = 4) -> None:
+        """Gather a list of C-contiguous uint8 [S,S,3] arrays into pinned slot 0/1 (C threads, GIL released)."""
+        ptrs = (c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        _lib.check(_lib.load().vq_encoder_stage_frames(self._h, int(slot), ptrs, len(frames), int(n_threads)))
+
+    def submit_staged(self, slot: int, n: int, swap_rb: bool = True) -> None:
+        """Enqueue upload → forward → download for the slot; returns immediately."""
+        _lib.check(_lib.load().vq_encoder_submit_staged(self._h, int(slot), int(n), int(bool(swap_rb))))
+
+    def wait_staged(self, slot: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.cfg.proj_dim), dtype=np.float32)
+        _lib.check(_lib.load().vq_encoder_wait_staged(self._h, int(slot), _lib.fptr(out)))
+        return out
+
+    def prewarm_staged(self) -> None:
+        """Allocate both pinned slots and their device/result buffers now (a one-frame pass through each) so the
+        first real ingest does not pay for it."""
+        for slot in (0, 1):
+            self.staging(slot)[0].fill(0)
+            self.submit_staged(slot, 1)
+            self.wait_staged(slot, 1)
+
     # -- device buffers (pointers, e.g. torch.Tensor.data_ptr()) ----------------
     def encode_device(self, d_frames: int, n: int, d_out_f32: int, d_out_f16: int = 0, swap_rb: bool = True) -> None:
         """Asynchronous on the encoder's stream; call synchronize() before reading."""
