@@ -584,6 +584,87 @@ def test_config2_batching_invariance(gpu_lib, b32_weights):
     a.close(); b.close()
 
 
+def test_config2_full_size_50k_frames(gpu_lib, b32_weights):
+    """configs[1] at its full size: 50,000 device-resident frames in 196 passes of 256 (the last one 80 frames).
+    Too many for the CPU oracle, so: every embedding is finite and unit-norm, the whole run is reproducible bit for
+    bit, the ragged last pass gives the bits a full pass gives for the same frames, and a sample of frames agrees
+    with the fp32 oracle to the parity bar."""
+    import torch
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    n, bsz = 50_000, 256
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(20250824)
+    frames = torch.randint(0, 255, (n, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)    # 7.5 GB
+    enc = VitEncoder(VIT_B_32, b32_weights, max_batch=bsz)
+
+    def run():
+        out = torch.empty((n, 512), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        passes = 0
+        for lo in range(0, n, bsz):
+            m = min(bsz, n - lo)
+            enc.encode_device(frames[lo:lo + m].data_ptr(), m, out[lo:lo + m].data_ptr())
+            passes += 1
+        enc.synchronize()
+        return out, passes
+
+    e1, passes = run()
+    assert passes == 196 and n - 195 * bsz == 80
+    assert bool(torch.isfinite(e1).all()) and float((e1.norm(dim=1) - 1).abs().max()) <= 1e-5
+    e2, _ = run()
+    assert torch.equal(e1, e2)                                                  # reproducible, all 50,000 x 512
+    tail = torch.empty((bsz, 512), dtype=torch.float32, device=dev)             # the last 80 frames inside a full pass
+    mixed = torch.cat([frames[n - 80:], frames[:bsz - 80]])
+    torch.cuda.synchronize()
+    enc.encode_device(mixed.data_ptr(), bsz, tail.data_ptr()); enc.synchronize()
+    assert torch.equal(tail[:80], e1[n - 80:]) and torch.equal(tail[80:], e1[:bsz - 80])
+    pick = [0, 255, 256, 12_345, 33_333, 49_919, 49_920, 49_999]                # pass boundaries and the ragged pass
+    ref = clip_vit_oracle.encode_frames(frames[pick].cpu().numpy(), b32_weights, batch_size=8)
+    cos = np.sum(e1[pick].cpu().numpy() * ref, axis=1)
+    assert cos.min() >= 1.0 - COS_TOL
+    enc.close()
+
+
+def test_config5_scale_index_8m_x_768(gpu_lib):
+    """configs[4]'s index at full size on one GPU: 8,000,000 x 768 (6.1e9 elements: every row offset needs 64
+    bits; fp32 master 24.6 GB + fp16 image 12.3 GB).  Properties: the fp16-scan result equals the independent exact
+    fp32-master scan bit for bit, lists are sorted by (distance, id), ids are in range, every query is accounted
+    for by the proof statistics, and rows queried against the index return themselves first."""
+    import torch
+    from video_quierer_amd.indexes.hnsw import MODE_EXACT, MODE_FP16, OptimizedHNSWIndex
+    n, d, chunk = 8_000_000, 768, 1_000_000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(555)
+    idx = OptimizedHNSWIndex(dimension=d)
+    keep = None
+    for c0 in range(0, n, chunk):
+        blk = torch.randn((chunk, d), device=dev, generator=g)
+        if c0 == 7 * chunk:
+            keep = (blk[-64:] / blk[-64:].norm(dim=1, keepdim=True)).clone()    # the last 64 rows (offsets > 2^32 elements)
+        torch.cuda.synchronize()
+        idx.add_device(blk.data_ptr(), chunk, range(c0, c0 + chunk), normalize=True)
+        idx.synchronize()
+        del blk
+    assert idx.size() == n
+    nq, k = 32, 10
+    probe = torch.randn((nq, d), device=dev, generator=g)
+    probe = torch.cat([probe / probe.norm(dim=1, keepdim=True), keep[:16]])   # 32 random directions + 16 stored rows
+    nq = probe.shape[0]
+    ids16 = torch.empty((nq, k), dtype=torch.int32, device=dev); d16 = torch.empty((nq, k), device=dev)
+    idsx = torch.empty((nq, k), dtype=torch.int32, device=dev); dx = torch.empty((nq, k), device=dev)
+    torch.cuda.synchronize()
+    idx.search_device(probe.data_ptr(), nq, k, ids16.data_ptr(), d16.data_ptr(), mode=MODE_FP16); idx.synchronize()
+    st = idx.last_search_stats()
+    idx.search_device(probe.data_ptr(), nq, k, idsx.data_ptr(), dx.data_ptr(), mode=MODE_EXACT); idx.synchronize()
+    assert torch.equal(ids16, idsx) and torch.equal(d16, dx)
+    assert st["verified"] + st["rescanned"] + st["exact_fallback"] == nq
+    dd, ii = d16.cpu().numpy(), ids16.cpu().numpy()
+    assert np.all(np.diff(dd, axis=1) >= 0) and np.all((ii >= 0) & (ii < n))
+    assert ii[32:, 0].tolist() == list(range(n - 64, n - 48)) and np.abs(dd[32:, 0]).max() <= 1e-5
+    idx.close()
+
+
 # ------------------------------------------------------------------ frame preprocessing in front of the encoder (§8f #3)
 @pytest.fixture(scope="module")
 def pre(gpu_lib):
