@@ -4,9 +4,6 @@
 // (staged through LDS row by row), the uint8 intermediate is the only extra traffic.
 #pragma once
 #include "vq_common.h"
-#ifndef RS_MUL
-#define RS_MUL(a, b) __mul24((a), (b))
-#endif
 
 namespace vq {
 
@@ -94,10 +91,10 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
             const int4 kq = k[q];
             const int k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;
             // weights are 23-bit signed, pixels 8-bit: v_mad_i32_i24 (full rate) instead of a 32-bit multiply
-            s0 += RS_MUL((int)(e0 & 255), k0);         s1 += RS_MUL((int)((e0 >> 8) & 255), k0);  s2 += RS_MUL((int)((e0 >> 16) & 255), k0);
-            s0 += RS_MUL((int)(e0 >> 24), k1);         s1 += RS_MUL((int)(e1 & 255), k1);         s2 += RS_MUL((int)((e1 >> 8) & 255), k1);
-            s0 += RS_MUL((int)((e1 >> 16) & 255), k2); s1 += RS_MUL((int)(e1 >> 24), k2);         s2 += RS_MUL((int)(e2 & 255), k2);
-            s0 += RS_MUL((int)((e2 >> 8) & 255), k3);  s1 += RS_MUL((int)((e2 >> 16) & 255), k3); s2 += RS_MUL((int)(e2 >> 24), k3);
+            s0 += __mul24((int)(e0 & 255), k0);         s1 += __mul24((int)((e0 >> 8) & 255), k0);  s2 += __mul24((int)((e0 >> 16) & 255), k0);
+            s0 += __mul24((int)(e0 >> 24), k1);         s1 += __mul24((int)(e1 & 255), k1);         s2 += __mul24((int)((e1 >> 8) & 255), k1);
+            s0 += __mul24((int)((e1 >> 16) & 255), k2); s1 += __mul24((int)(e1 >> 24), k2);         s2 += __mul24((int)(e2 & 255), k2);
+            s0 += __mul24((int)((e2 >> 8) & 255), k3);  s1 += __mul24((int)((e2 >> 16) & 255), k3); s2 += __mul24((int)(e2 >> 24), k3);
             d0 = d3;
             di += 3;
         }
