@@ -599,13 +599,15 @@ void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restr
 // flight while the current one is consumed.  (The per-wave version re-read K and V from global memory
 // once per query tile and ran at ~280 TFLOP/s on ViT-L/14@336, 32 % of that model's step.)
 template <bool F16, bool CAUSAL>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                 int tokens, int hidden, int heads, int q_tiles, int q_groups) {
     __shared__ __attribute__((aligned(16))) uint16_t klds[2][64 * 64];
     __shared__ __attribute__((aligned(16))) uint16_t vlds[2][64 * 64];
     typedef mfma_op<F16> op;
     typedef typename op::frag frag;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qg = blockIdx.x % q_groups;
@@ -617,6 +619,13 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     const uint16_t* base = qkv + (size_t)img * tokens * ld + head * 64;
     const int r16 = lane & 15, g = lane >> 4;
     const int q0 = qt * 64;
+
+    // Rows past `tokens` are never written by the tile loads below; zero both buffers once so that whatever a
+    // masked key position holds is finite (its probability is 0, and 0 * finite = 0 in the P.V product).
+    for (int i = tid; i < 2 * 64 * 64 / 8; i += 256) {
+        ((uint4*)&klds[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+        ((uint4*)&vlds[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+    }
 
     frag qf[4][2];
 #pragma unroll
@@ -635,6 +644,8 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float NEGBIG = -3.0e38f;
+    const float L2E = 1.44269504088896341f;
+    // running maximum in the log2 domain (score * log2 e): p = exp2(score * log2e - m2) is one fma + one v_exp
     float m_run[4] = {NEGBIG, NEGBIG, NEGBIG, NEGBIG}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int all_k_tiles = (tokens + 63) / 64;
@@ -642,26 +653,23 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     const int wg_k_tiles = CAUSAL ? min(all_k_tiles, last_q_tile + 1) : all_k_tiles;   // key steps the workgroup walks
     const int my_k_tiles = !live ? 0 : (CAUSAL ? qt + 1 : all_k_tiles);
 
-    // cooperative tile load: thread -> (row = tid >> 2 .. , two 16-byte chunks)
-    const int lrow = tid >> 2, lc = (tid & 3) * 2;            // 64 rows x 8 chunks; each thread 2 chunks
-    uint4 kreg[2], vreg[2];
-    auto fetch = [&](int kt) __attribute__((always_inline)) {
-        const int row = kt * 64 + lrow;
+    // Tile loads by LDS-DMA (no register round trip): a 64 x 64 tile is 512 16-byte positions; thread tid fills
+    // positions tid and 256 + tid (row = pos >> 3, physical chunk = pos & 7).  K is stored XOR-swizzled for
+    // conflict-free ds_read_b128 fragments, so the lane that owns physical chunk c fetches logical chunk
+    // c ^ ((row >> 1) & 7); V is row-major for the transposed reads.
+    auto fetch = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            kreg[i] = uint4{0u, 0u, 0u, 0u}; vreg[i] = uint4{0u, 0u, 0u, 0u};
-            if (row < tokens) {
-                kreg[i] = *(const uint4*)(base + hidden + (size_t)row * ld + (lc + i) * 8);
-                vreg[i] = *(const uint4*)(base + 2 * hidden + (size_t)row * ld + (lc + i) * 8);
+        for (int sl = 0; sl < 2; ++sl) {
+            const int pos = sl * 256 + tid;
+            const int row = pos >> 3, cp = pos & 7;
+            const int grow = kt * 64 + row;
+            if (grow < tokens) {
+                const uint16_t* src = base + (size_t)grow * ld;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src + hidden + (cp ^ ((row >> 1) & 7)) * 8),
+                                                 (lds_void*)(&klds[buf][sl * 2048 + wave * 512]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src + 2 * hidden + cp * 8),
+                                                 (lds_void*)(&vlds[buf][sl * 2048 + wave * 512]), 16, 0, 0);
             }
-        }
-    };
-    auto commit = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = lc + i;
-            *(uint4*)(klds[buf] + lrow * 64 + ((c ^ ((lrow >> 1) & 7)) * 8)) = kreg[i];     // swizzled K image
-            *(uint4*)(vlds[buf] + lrow * 64 + c * 8) = vreg[i];                            // row-major V image
         }
     };
     const int q4 = r16 >> 2, p4 = r16 & 3;
@@ -669,12 +677,13 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int kfx = (r16 >> 1) & 7;
 
-    fetch(0);
-    commit(0);
+    __syncthreads();                                        // zero fill done before the first tile lands
+    fetch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < wg_k_tiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < wg_k_tiles) fetch(kt + 1);             // global loads in flight during this step's math
+        if (kt + 1 < wg_k_tiles) fetch(kt + 1, buf ^ 1);    // the other buffer was last read in step kt-1 (barrier below it)
         if (kt < my_k_tiles) {
             const int k0 = kt * 64;
             const uint16_t* kt_l = klds[buf];
@@ -685,79 +694,89 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     kf[t][ks] = *(const frag*)(kt_l + (t * 16 + r16) * 64 + (((ks * 4 + g) ^ kfx) * 8));
-            f32x4 sc[4][4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = op::run(kf[mt][0], qf[nt][0], a);
-                    a = op::run(kf[mt][1], qf[nt][1], a);
-                    sc[mt][nt] = a;
-                }
-            float alpha[4];
             const bool edge = (k0 + 64 > tokens) || (CAUSAL && kt == qt);      // only these tiles need masking
+            // the 64 query rows of the wave are independent: two passes of 32 rows keep the live score /
+            // probability registers at half (the whole kernel then fits 2 waves per SIMD)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int query = q0 + nt * 16 + r16;
-                float mx = NEGBIG;
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 sc[4][2];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (edge) {
-                            const int key = k0 + mt * 16 + g * 4 + r;
-                            if (key >= tokens || (CAUSAL && key > query)) sc[mt][nt][r] = NEGBIG;
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                        a = op::run(kf[mt][0], qf[2 * hh + j][0], a);
+                        a = op::run(kf[mt][1], qf[2 * hh + j][1], a);
+                        sc[mt][j] = a;
+                    }
+                float alpha[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nt = 2 * hh + j;
+                    const int query = q0 + nt * 16 + r16;
+                    float mx = NEGBIG;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (edge) {
+                                const int key = k0 + mt * 16 + g * 4 + r;
+                                if (key >= tokens || (CAUSAL && key > query)) sc[mt][j][r] = NEGBIG;
+                            }
+                            mx = fmaxf(mx, sc[mt][j][r]);
                         }
-                        mx = fmaxf(mx, sc[mt][nt][r]);
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[nt], mx);
-                alpha[nt] = __expf(m_run[nt] - m_new);
-                float sum = 0.f;
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float m_new = fmaxf(m_run[nt], mx * L2E);
+                    alpha[j] = __builtin_amdgcn_exp2f(m_run[nt] - m_new);
+                    float sum = 0.f;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float p = __expf(sc[mt][nt][r] - m_new);
-                        if (edge && sc[mt][nt][r] <= NEGBIG) p = 0.f;
-                        sc[mt][nt][r] = p;
-                        sum += p;
+                        for (int r = 0; r < 4; ++r) {
+                            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mt][j][r], L2E, -m_new));
+                            if (edge && sc[mt][j][r] <= NEGBIG) p = 0.f;
+                            sc[mt][j][r] = p;
+                            sum += p;
+                        }
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    l_run[nt] = l_run[nt] * alpha[j] + sum;
+                    m_run[nt] = m_new;
+                }
+                // the running maximum settles after the first tiles: rescale the accumulators only when some row's moved
+                if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.0f || alpha[1] != 1.0f) != 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4& oo = o[dt][2 * hh + j];
+                            oo[0] *= alpha[j]; oo[1] *= alpha[j]; oo[2] *= alpha[j]; oo[3] *= alpha[j];
+                        }
+                }
+                frag pf[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss) {
+                        const uint2 plo = pack4_h<F16>(sc[2 * ss][j]), phi = pack4_h<F16>(sc[2 * ss + 1][j]);
+                        pf[j][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                l_run[nt] = l_run[nt] * alpha[nt] + sum;
-                m_run[nt] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss) {
+                        const int key0 = 32 * ss + 4 * g + q4;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + key0 * 64 + dt * 16 + p4 * 4));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + (key0 + 16) * 64 + dt * 16 + p4 * 4));
+                        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const frag vf = __builtin_bit_cast(frag, both);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) o[dt][2 * hh + j] = op::run(vf, pf[j][ss], o[dt][2 * hh + j]);
+                    }
             }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    o[dt][nt][0] *= alpha[nt]; o[dt][nt][1] *= alpha[nt]; o[dt][nt][2] *= alpha[nt]; o[dt][nt][3] *= alpha[nt];
-                }
-            frag pf[4][2];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const uint2 plo = pack4_h<F16>(sc[2 * ss][nt]), phi = pack4_h<F16>(sc[2 * ss + 1][nt]);
-                    pf[nt][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
-                }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const int key0 = 32 * ss + 4 * g + q4;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + key0 * 64 + dt * 16 + p4 * 4));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt + (key0 + 16) * 64 + dt * 16 + p4 * 4));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const frag vf = __builtin_bit_cast(frag, both);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) o[dt][nt] = op::run(vf, pf[nt][ss], o[dt][nt]);
-                }
         }
-        if (kt + 1 < wg_k_tiles) commit(buf ^ 1);            // the other buffer was last read in step kt-1 (barrier below it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed
         __syncthreads();
     }
     if (!live) return;
