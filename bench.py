@@ -77,12 +77,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switches (not used by the driver): run all ranks on one device over gloo to exercise the N>1 code path
+    if os.environ.get("VQ_BENCH_DEVICE") is not None:
+        local = int(os.environ["VQ_BENCH_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("VQ_BENCH_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(os.environ["VQ_BENCH_BACKEND"])
 
     from video_quierer_amd import _lib
     from video_quierer_amd.encoder import VitEncoder
