@@ -221,6 +221,11 @@ int vq_index_last_search_stats(vq_index* idx, int64_t* stats /*[3]*/);
  * out [n][crop_h][crop_w][3]. */
 #define VQ_RESAMPLE_BILINEAR 2      /* PIL.Image.BILINEAR */
 #define VQ_RESAMPLE_BICUBIC 3       /* PIL.Image.BICUBIC */
+/* cv2.resize(frame, (out_w, out_h)) with the default INTER_LINEAR — what OptimizedFrameExtractor applies
+ * (frame_extractor.py:283-284): OpenCV's 11-bit two-tap bilinear without antialiasing, its exact-2x shortcut
+ * to the 2x2 area average, equal sizes copied.  OpenCV is absent from the build container: restated from
+ * modules/imgproc/src/resize.cpp, parity unpinned. */
+#define VQ_RESAMPLE_CV_LINEAR 100
 typedef struct vq_resampler vq_resampler;
 int vq_resampler_create(vq_resampler** out);
 int vq_resampler_destroy(vq_resampler* r);

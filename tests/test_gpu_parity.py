@@ -760,6 +760,26 @@ def test_feature_extractor_resizes_on_gpu(gpu_lib, b32_weights):
     fx.thread_pool.shutdown(); fx2.thread_pool.shutdown()
 
 
+def test_cv_resize_vs_oracle(pre):
+    """cv2.resize(frame, (w, h)) restated (INTER_LINEAR, parity unpinned vs OpenCV): the GPU kernel equals the numpy
+    restatement bit for bit on down-scales, up-scales, the exact-2x shortcut, equal sizes and crop windows."""
+    from oracle import cv_resize_oracle as cv
+    rng = np.random.default_rng(15)
+    for (h, w, ow, oh) in [(1080, 1920, 224, 224), (720, 1280, 224, 224), (448, 448, 224, 224), (100, 80, 224, 224),
+                           (224, 224, 224, 224), (37, 53, 7, 5), (2, 3, 9, 4), (1, 1, 3, 3), (480, 640, 320, 240), (300, 400, 401, 299)]:
+        n = 2 if h * w < 400000 else 1
+        frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        ref = np.stack([cv.resize_linear_u8(f, ow, oh) for f in frames])
+        assert np.array_equal(pre.cv_resize(frames, (ow, oh)), ref), (h, w, ow, oh)
+        if ow >= 4 and oh >= 4:
+            win = (oh // 4, ow // 4, oh // 2, ow // 2)
+            got = pre.cv_resize(frames, (ow, oh), crop=win)
+            assert np.array_equal(got, ref[:, win[0]:win[0] + win[2], win[1]:win[1] + win[3]])
+    # a Pillow resize after it on the same handle still uses its own tables
+    f = rng.integers(0, 256, (1, 90, 160, 3), dtype=np.uint8)
+    a = pre.stretch(f); pre.cv_resize(f, (224, 224)); assert np.array_equal(pre.stretch(f), a)
+
+
 def test_frame_quality_vs_oracle(pre):
     """np.mean(frame) exactly; Laplacian variance from exact integer sums vs numpy's float64 two-pass (1e-12);
     the low-quality decision of reference frame_extractor.py:301-316 on dark / bright / flat / textured frames."""

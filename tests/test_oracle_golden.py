@@ -172,3 +172,19 @@ def test_quality_oracle_properties():
     chk = np.indices((6, 6)).sum(0) % 2 * 255
     L = q.laplacian_f64(chk.astype(np.uint8))
     assert np.array_equal(np.abs(L), np.full((6, 6), 1020.0))                         # checkerboard: |L| = 4*255 everywhere (reflect-101 keeps parity)
+
+
+def test_cv_resize_oracle_properties():
+    """Parity unpinned (OpenCV absent): invariants of the INTER_LINEAR restatement."""
+    from oracle import cv_resize_oracle as cv, resample_oracle as ro
+    rng = np.random.default_rng(21)
+    assert np.unique(cv.resize_linear_u8(np.full((37, 53, 3), 137, np.uint8), 224, 224)).tolist() == [137]   # weights sum to one
+    img = rng.integers(0, 256, (100, 80, 3), dtype=np.uint8)
+    assert np.array_equal(cv.resize_linear_u8(img, 80, 100), img)                                            # equal size = copy
+    big = rng.integers(0, 256, (448, 448, 3), dtype=np.uint8).astype(np.int64)
+    half = cv.resize_linear_u8(big.astype(np.uint8), 224, 224)
+    assert np.array_equal(half, (big[0::2, 0::2] + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2)
+    up = cv.resize_linear_u8(img, 224, 224)                 # up-scaling needs no antialiasing: Pillow's bilinear is the same map
+    assert np.abs(up.astype(int) - ro.resize_u8(img, 224, 224, ro.BILINEAR)).max() <= 1
+    s, w0, w1 = cv.linear_coeffs(1920, 224, True)
+    assert np.all(w0 + w1 == 2048) and s.min() >= 0 and s.max() <= 1919 and np.all(np.diff(s) > 0)

@@ -156,6 +156,48 @@ void resample_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ ds
     }
 }
 
+// ---- cv2.resize(frame, (w, h)), INTER_LINEAR, 8-bit (reference frame_extractor.py:283-284) --------------
+// OpenCV's two-tap fixed-point bilinear: 11-bit weights, 32-bit horizontal sums, the VResizeLinear<uchar>
+// rounding.  No antialiasing, so a thread reads 4 source pixels per output pixel: one thread per output byte.
+//   xofs/yofs: first tap per output column / row; wx, wy: the two short weights per column / row
+//   out [n][crop_h][crop_w][3] = window (crop_top, crop_left) of the resized frame
+__global__ __launch_bounds__(RS_THREADS)
+void cv_resize_linear_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                             const int* __restrict__ xofs, const int* __restrict__ wx,
+                             const int* __restrict__ yofs, const int* __restrict__ wy,
+                             int h, int w, int crop_top, int crop_left, int crop_h, int crop_w) {
+    const int j = blockIdx.x * RS_THREADS + threadIdx.x;            // byte inside the output row
+    const int yo = blockIdx.y, img = blockIdx.z;
+    if (j >= crop_w * 3) return;
+    const int xo = j / 3, c = j - xo * 3;
+    const int dx = crop_left + xo, dy = crop_top + yo;
+    const int sx = xofs[dx], sx1 = min(sx + 1, w - 1);
+    const int a0 = wx[2 * dx], a1 = wx[2 * dx + 1];
+    const int sy = yofs[dy];
+    const int y0 = min(max(sy, 0), h - 1), y1 = min(max(sy + 1, 0), h - 1);
+    const int b0 = wy[2 * dy], b1 = wy[2 * dy + 1];
+    const uint8_t* f = src + (size_t)img * h * w * 3;
+    const uint8_t* r0 = f + (size_t)y0 * w * 3;
+    const uint8_t* r1 = f + (size_t)y1 * w * 3;
+    const int d0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+    const int d1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+    const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+    dst[((size_t)img * crop_h + yo) * crop_w * 3 + j] = (uint8_t)v;
+}
+
+// exact 2x2 down-scale: cv2 routes INTER_LINEAR to INTER_AREA's fast path, (a + b + c + d + 2) >> 2
+__global__ __launch_bounds__(RS_THREADS)
+void cv_resize_half_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                           int h, int w, int crop_top, int crop_left, int crop_h, int crop_w) {
+    const int j = blockIdx.x * RS_THREADS + threadIdx.x;
+    const int yo = blockIdx.y, img = blockIdx.z;
+    if (j >= crop_w * 3) return;
+    const int xo = j / 3, c = j - xo * 3;
+    const uint8_t* p = src + (((size_t)img * h + 2 * (crop_top + yo)) * w + 2 * (crop_left + xo)) * 3 + c;
+    const size_t pitch = (size_t)w * 3;
+    dst[((size_t)img * crop_h + yo) * crop_w * 3 + j] = (uint8_t)((p[0] + p[3] + p[pitch] + p[pitch + 3] + 2) >> 2);
+}
+
 // ---- frame quality (reference frame_extractor.py:301-316) ------------------------------------------------
 // per frame: sum of all bytes (np.mean(frame)), and over the grey image g = BGR2GRAY(frame) the sums of
 // L and L^2 where L = cv2.Laplacian(g, CV_64F) (aperture 1: the 4-neighbour stencil, BORDER_REFLECT_101).

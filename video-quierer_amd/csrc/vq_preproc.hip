@@ -66,6 +66,29 @@ static void precompute_coeffs(int in_size, int out_size, int filter, Coeffs& c) 
     }
 }
 
+// OpenCV resize.cpp INTER_LINEAR tables for one axis: first tap and the two 11-bit weights per output index.
+// snap_borders = the horizontal rule (weight 1 on the edge pixel outside [0, src-1)); rows are clipped by the kernel.
+static void cv_linear_coeffs(int src, int dst, bool snap_borders, std::vector<int>& ofs, std::vector<int>& wts) {
+    const double scale = (double)src / dst;
+    ofs.resize(dst); wts.resize((size_t)dst * 2);
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (snap_borders) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= src - 1) { f = 0.f; s = src - 1; }
+        }
+        auto sat_short = [](float v) {                       // saturate_cast<short>(v): cvRound (half to even) + clamp
+            long r = std::lrint(v);
+            return (int)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+        };
+        ofs[d] = s;
+        wts[2 * d] = sat_short((1.f - f) * 2048.f);
+        wts[2 * d + 1] = sat_short(f * 2048.f);
+    }
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -118,7 +141,8 @@ int check_geometry(const char* who, int n, int h, int w, int filter, int out_h, 
                    int crop_top, int crop_left, int crop_h, int crop_w) {
     VQ_CHECK(n >= 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "%s: sizes must be positive (n=%d h=%d w=%d out=%dx%d)",
              who, n, h, w, out_h, out_w);
-    VQ_CHECK(filter == VQ_RESAMPLE_BILINEAR || filter == VQ_RESAMPLE_BICUBIC, "%s: filter %d is not BILINEAR(2) or BICUBIC(3)", who, filter);
+    VQ_CHECK(filter == VQ_RESAMPLE_BILINEAR || filter == VQ_RESAMPLE_BICUBIC || filter == VQ_RESAMPLE_CV_LINEAR,
+             "%s: filter %d is not BILINEAR(2), BICUBIC(3) or CV_LINEAR(100)", who, filter);
     VQ_CHECK(crop_h > 0 && crop_w > 0 && crop_top >= 0 && crop_left >= 0 && crop_top + crop_h <= out_h && crop_left + crop_w <= out_w,
              "%s: crop %dx%d at (%d,%d) does not fit the %dx%d resized frame", who, crop_h, crop_w, crop_top, crop_left, out_h, out_w);
     VQ_CHECK((int64_t)h * w < (int64_t)1 << 30, "%s: frame of %dx%d pixels is too large", who, h, w);
@@ -127,8 +151,44 @@ int check_geometry(const char* who, int n, int h, int w, int filter, int out_h, 
 }
 
 // both passes for n device-resident frames; d_dst gets [n][crop_h][crop_w][3]
+// cv2.resize(frame, (out_w, out_h)) — INTER_LINEAR
+int run_device_cv(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int out_h, int out_w,
+                  int crop_top, int crop_left, int crop_h, int crop_w, uint8_t* d_dst) {
+    const dim3 grid(cdiv(crop_w * 3, RS_THREADS), crop_h, n);
+    if (out_h == h && out_w == w && crop_top == 0 && crop_left == 0 && crop_h == h && crop_w == w) {
+        VQ_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)n * h * w * 3, hipMemcpyDeviceToDevice, r->stream));
+        return 0;
+    }
+    if (h == 2 * out_h && w == 2 * out_w) {
+        hipLaunchKernelGGL(cv_resize_half_kernel, grid, dim3(RS_THREADS), 0, r->stream, d_src, d_dst, h, w, crop_top, crop_left,
+                           crop_h, crop_w);
+        VQ_HIP(hipGetLastError());
+        return 0;
+    }
+    if (!(r->p_h == h && r->p_w == w && r->p_filter == VQ_RESAMPLE_CV_LINEAR && r->p_out_h == out_h && r->p_out_w == out_w)) {
+        VQ_HIP(hipStreamSynchronize(r->stream));
+        std::vector<int> xo, wx, yo, wy;
+        cv_linear_coeffs(w, out_w, true, xo, wx);
+        cv_linear_coeffs(h, out_h, false, yo, wy);
+        const size_t total = xo.size() + wx.size() + yo.size() + wy.size();
+        VQ_TRY(r->coef.reserve(total * sizeof(int)));
+        r->d_bh = (int*)r->coef.p; r->d_kh = r->d_bh + xo.size(); r->d_bv = r->d_kh + wx.size(); r->d_kv = r->d_bv + yo.size();
+        VQ_HIP(hipMemcpy(r->d_bh, xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
+        VQ_HIP(hipMemcpy(r->d_kh, wx.data(), wx.size() * 4, hipMemcpyHostToDevice));
+        VQ_HIP(hipMemcpy(r->d_bv, yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
+        VQ_HIP(hipMemcpy(r->d_kv, wy.data(), wy.size() * 4, hipMemcpyHostToDevice));
+        r->p_h = h; r->p_w = w; r->p_filter = VQ_RESAMPLE_CV_LINEAR; r->p_out_h = out_h; r->p_out_w = out_w;
+    }
+    hipLaunchKernelGGL(cv_resize_linear_kernel, grid, dim3(RS_THREADS), 0, r->stream, d_src, d_dst, r->d_bh, r->d_kh, r->d_bv,
+                       r->d_kv, h, w, crop_top, crop_left, crop_h, crop_w);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int filter, int out_h, int out_w,
                int crop_top, int crop_left, int crop_h, int crop_w, uint8_t* d_dst) {
+    if (filter == VQ_RESAMPLE_CV_LINEAR)
+        return run_device_cv(r, d_src, n, h, w, out_h, out_w, crop_top, crop_left, crop_h, crop_w, d_dst);
     VQ_TRY(plan(r, h, w, filter, out_h, out_w));
     const int* bv = r->cv.bounds.data();
     const int row_first = bv[2 * crop_top];

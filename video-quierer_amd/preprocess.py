@@ -5,6 +5,8 @@ frame-quality statistics of the reference's frame extractor, over ``vq_resampler
     src/core/feature_extractor.py:54-61 (PIL bilinear, antialiased);
   * :meth:`FramePreprocessor.clip_processor` — the CLIP image processor of the live path
     (reference video_search_overhaul.py:129-135, :218-221): short edge → 224 bicubic, centre crop 224;
+  * :meth:`FramePreprocessor.cv_resize` — ``cv2.resize(frame, frame_size)`` of reference
+    src/core/frame_extractor.py:283-284 (OpenCV INTER_LINEAR; parity unpinned);
   * :meth:`FramePreprocessor.quality` / :meth:`is_low_quality` — reference
     src/core/frame_extractor.py:301-316.
 """
@@ -17,6 +19,7 @@ import numpy as np
 from . import _lib
 
 BILINEAR, BICUBIC = 2, 3            # PIL.Image.Resampling values (VQ_RESAMPLE_*)
+CV_LINEAR = 100                     # cv2.resize's default INTER_LINEAR (VQ_RESAMPLE_CV_LINEAR)
 
 
 def clip_processor_geometry(h: int, w: int, size: int = 224, crop: int = 224) -> Tuple[int, int, int, int]:
@@ -110,6 +113,12 @@ class FramePreprocessor:
         ptr = c_void_p()
         _lib.check(_lib.load().vq_resampler_device_output(self._h, ctypes.byref(ptr), None))
         return ptr.value
+
+    def cv_resize(self, frames, dsize: Tuple[int, int], **kw):
+        """``cv2.resize(frame, dsize)`` (dsize = (width, height), INTER_LINEAR) of every frame — the resize of
+        ``OptimizedFrameExtractor.extract_frames`` (reference frame_extractor.py:283-284).  Restated from OpenCV's
+        published algorithm; parity unpinned (OpenCV is not installed in the build container)."""
+        return self.resize(frames, int(dsize[1]), int(dsize[0]), CV_LINEAR, **kw)
 
     def stretch(self, frames, size: int = 224, **kw):
         """E1's ``transforms.Resize((S, S))`` (reference feature_extractor.py:55)."""
