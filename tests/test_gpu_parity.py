@@ -829,3 +829,19 @@ def test_pipelined_ingest_matches_single_pass(gpu_lib):
     with pytest.raises(ValueError):
         m.wait_staged(0, 4)                            # nothing in flight
     fx.thread_pool.shutdown()
+
+
+def test_ingest_recovers_after_a_bad_frame(gpu_lib):
+    """An exception in the middle of a pipelined ingest (a frame of the wrong dtype) propagates, as the reference's
+    extract_from_video_frames re-raises (:207-209), and leaves the extractor usable: in-flight slots are drained."""
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=16)
+    frames = list(synth_frames(96, seed=41))
+    fds = [{"frame": f, "frame_number": i} for i, f in enumerate(frames)]
+    bad = [dict(fd) for fd in fds]
+    bad[70]["frame"] = frames[70].astype(np.float32)
+    with pytest.raises(TypeError):
+        fx.extract_from_video_frames(bad)
+    again = fx.extract_from_video_frames(fds)
+    assert len(again) == 96 and np.abs(np.stack([o["features"] for o in again]) - fx.model.encode(np.stack(frames))).max() <= 2e-6
+    fx.thread_pool.shutdown()

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import asyncio
 import logging
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Sequence, Union
@@ -66,6 +67,7 @@ class FeatureExtractor:
         self.resize_mode = resize_mode
         self.ingest_streams = int(ingest_streams)     # encoder handles a long extract_from_video_frames alternates between
         self._ingest: List[VitEncoder] = []
+        self._ingest_lock = threading.Lock()
         self.model_name = model_name
         self.batch_size = batch_size
         self.num_threads = num_threads
@@ -225,6 +227,59 @@ class FeatureExtractor:
             logger.error(f"Feature extraction failed: {e}")
             raise
 
+    def _run_ingest(self, chunks, start_time: float, results: List[Dict[str, Any]]) -> None:
+        models = self._ingest_models(len(chunks))
+        nm = len(models)
+        views: Dict[Any, np.ndarray] = {}
+
+        def stage(ci):
+            """Host side of pass ci: frames -> pinned slot, then enqueue upload/forward/download."""
+            model, slot = models[ci % nm], (ci // nm) & 1
+            frames = [fd["frame"] for fd in chunks[ci]]
+            if self._all_native_ndarrays(frames):
+                model.stage_frames(slot, frames, max(self.num_threads, 8))   # C gather (memcpy threads), no per-frame Python work
+                swap = True
+            else:
+                if (ci % nm, slot) not in views:
+                    views[(ci % nm, slot)] = model.staging(slot)
+                _, swap = self._preprocess_batch(frames, views[(ci % nm, slot)])
+            model.submit_staged(slot, len(frames), swap_rb=swap)
+
+        def collect(ci):
+            chunk = chunks[ci]
+            feats = models[ci % nm].wait_staged((ci // nm) & 1, len(chunk))
+            self.total_processed += len(chunk)
+            now = time.time() - start_time
+            for fd, f in zip(chunk, feats):
+                r = fd.copy()
+                r["features"] = f
+                r["feature_extraction_time"] = now
+                results.append(r)
+
+        depth = 2 * nm - 1          # passes in flight; pass ci reuses the slot of pass ci - 2*nm, collected by then
+        t0 = time.time()
+        staged = collected = 0
+        try:
+            for ci in range(len(chunks)):
+                if ci >= depth:
+                    collect(ci - depth)
+                    collected += 1
+                    self.extraction_times.append(time.time() - t0)
+                    t0 = time.time()
+                stage(ci)
+                staged += 1
+            while collected < len(chunks):
+                collect(collected)
+                collected += 1
+                self.extraction_times.append(time.time() - t0)
+                t0 = time.time()
+        finally:
+            for ci in range(collected, staged):      # an error left passes in flight: drain their slots for the next ingest
+                try:
+                    models[ci % nm].wait_staged((ci // nm) & 1, len(chunks[ci]))
+                except Exception:
+                    pass
+
     def extract_from_video_frames(self, frames_data: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         """Reference :179-209.  Frames are independent, so several ``batch_size`` slices are encoded in one
         device pass (up to ``device_batch`` frames); the host gather and the upload of the next pass overlap the
@@ -238,46 +293,8 @@ class FeatureExtractor:
         chunks = [frames_data[i:i + step] for i in range(0, len(frames_data), step)]
         results = []
         try:
-            models = self._ingest_models(len(chunks))
-            nm = len(models)
-            views: Dict[Any, np.ndarray] = {}
-
-            def stage(ci):
-                """Host side of pass ci: frames -> pinned slot, then enqueue upload/forward/download."""
-                model, slot = models[ci % nm], (ci // nm) & 1
-                frames = [fd["frame"] for fd in chunks[ci]]
-                if self._all_native_ndarrays(frames):
-                    model.stage_frames(slot, frames, max(self.num_threads, 8))   # C gather (memcpy threads), no per-frame Python work
-                    swap = True
-                else:
-                    if (ci % nm, slot) not in views:
-                        views[(ci % nm, slot)] = model.staging(slot)
-                    _, swap = self._preprocess_batch(frames, views[(ci % nm, slot)])
-                model.submit_staged(slot, len(frames), swap_rb=swap)
-
-            def collect(ci):
-                chunk = chunks[ci]
-                feats = models[ci % nm].wait_staged((ci // nm) & 1, len(chunk))
-                self.total_processed += len(chunk)
-                now = time.time() - start_time
-                for fd, f in zip(chunk, feats):
-                    r = fd.copy()
-                    r["features"] = f
-                    r["feature_extraction_time"] = now
-                    results.append(r)
-
-            depth = 2 * nm - 1          # passes in flight; pass ci reuses the slot of pass ci - 2*nm, collected by then
-            t0 = time.time()
-            for ci in range(len(chunks)):
-                if ci >= depth:
-                    collect(ci - depth)
-                    self.extraction_times.append(time.time() - t0)
-                    t0 = time.time()
-                stage(ci)
-            for ci in range(max(0, len(chunks) - depth), len(chunks)):
-                collect(ci)
-                self.extraction_times.append(time.time() - t0)
-                t0 = time.time()
+            with self._ingest_lock:          # the pinned slots belong to one ingest at a time
+                self._run_ingest(chunks, start_time, results)
         except Exception as e:
             logger.error(f"Feature extraction failed: {e}")
             raise

@@ -373,6 +373,7 @@ int vq_frame_quality_u8(vq_resampler* r, const uint8_t* frames, int n, int h, in
     VQ_TRY(require_init());
     VQ_CHECK(r && n >= 0 && h > 0 && w > 0 && (n == 0 || (frames && mean_brightness && laplacian_var)), "vq_frame_quality_u8: bad argument");
     VQ_CHECK((int64_t)h * w < (int64_t)1 << 30, "vq_frame_quality_u8: frame of %dx%d pixels is too large", h, w);
+    VQ_CHECK(n <= 65535, "vq_frame_quality_u8: at most 65535 frames per call");
     if (n == 0) return 0;
     std::lock_guard<std::mutex> lk(r->mu);
     const size_t frame_bytes = (size_t)h * w * 3;
