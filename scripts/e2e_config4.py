@@ -16,9 +16,14 @@ from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
 from video_quierer_amd.distributed import shard_range, all_gather_rows
 
 rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+if os.environ.get("VQ_BENCH_DEVICE") is not None:                  # rehearsal: every rank on one device, e.g. over gloo
+    local = int(os.environ["VQ_BENCH_DEVICE"])
 if world > 1:
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if os.environ.get("VQ_BENCH_BACKEND", "nccl") == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(os.environ["VQ_BENCH_BACKEND"])
 VIDEOS, FRAMES, NQ, K = 4, 1000, 1000, 10
 lo, hi = shard_range(VIDEOS * FRAMES, rank, world)                 # contiguous frame range of this rank
 rng = np.random.default_rng(1000 + rank)
