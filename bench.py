@@ -103,7 +103,8 @@ def main():
     # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=nstreams > 1)
+    conc = nstreams > 1 if os.environ.get("VQ_BENCH_CONCURRENT") is None else os.environ["VQ_BENCH_CONCURRENT"] == "1"
+    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=conc)
             for _ in range(nstreams)]
     for e_, s_ in zip(encs, streams):
         e_.set_stream(s_.cuda_stream)

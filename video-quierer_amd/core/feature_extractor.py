@@ -256,7 +256,7 @@ class FeatureExtractor:
                 r["feature_extraction_time"] = now
                 results.append(r)
 
-        depth = 2 * nm - 1          # passes in flight; pass ci reuses the slot of pass ci - 2*nm, collected by then
+        depth = 2 * nm              # passes in flight: pass ci reuses the slot of pass ci - 2*nm, which is collected first
         t0 = time.time()
         staged = collected = 0
         try:
