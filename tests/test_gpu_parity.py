@@ -37,6 +37,21 @@ def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     assert np.array_equal(debug_gemm(a, w, kernel=kernel), a @ w.T)
 
 
+def test_gemm_auto_tail_split_is_exact(gpu_lib):
+    """300 tiles of 256x256 = one full round of 256 CUs + 44: the auto dispatch sends the thin round's rows to the
+    128x128 kernel (two launches); integer data -> exact, and identical to the single-kernel result."""
+    from video_quierer_amd.encoder import debug_gemm
+    rng = np.random.default_rng(2)
+    m, n, k = 7680, 2560, 128
+    a = rng.integers(-3, 4, (m, k)).astype(np.float32)
+    w = rng.integers(-3, 4, (n, k)).astype(np.float32)
+    c = debug_gemm(a, w, kernel=0)
+    assert np.array_equal(c, a @ w.T)
+    ar = rng.standard_normal((m, k)).astype(np.float32)
+    wr = rng.standard_normal((n, k)).astype(np.float32)
+    assert np.array_equal(debug_gemm(ar, wr, kernel=0), debug_gemm(ar, wr, kernel=2))      # bit-identical to one 256x256 launch
+
+
 @pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
 def test_gemm_mfma_random(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm

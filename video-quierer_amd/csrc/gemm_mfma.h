@@ -136,7 +136,7 @@ template <bool IS_F16, class Epi>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                     const uint16_t* __restrict__ W, int ldw,
-                    int K, int tiles_n, Epi epi) {
+                    int K, int tiles_n, Epi epi, int m_base) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
@@ -147,7 +147,7 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
     const int wm = wave >> 1, wn = wave & 1;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (wg / tiles_n) * GEMM_BM;
+    const int m0 = m_base + (wg / tiles_n) * GEMM_BM;        // m_base: first row of the strip this launch covers
     const int n0 = (wg % tiles_n) * GEMM_BN;
 
     // ---- staging addresses (per lane source, wave-uniform LDS destination) ----
@@ -224,14 +224,14 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
 
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
-                          int M, int N, int K, const Epi& epi) {
+                          int M, int N, int K, const Epi& epi, int m_base = 0) {
     VQ_CHECK(M > 0 && M % GEMM_BM == 0 && N % GEMM_BN == 0 && K % GEMM_BK == 0 && K >= GEMM_BK,
              "gemm_tn: shape M=%d N=%d K=%d is not tile-aligned (128/128/64)", M, N, K);
     VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
              "gemm_tn: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
     const int tiles_m = M / GEMM_BM, tiles_n = N / GEMM_BN;
     hipLaunchKernelGGL((gemm_tn_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, st,
-                       A, lda, W, ldw, K, tiles_n, epi);
+                       A, lda, W, ldw, K, tiles_n, epi, m_base);
     VQ_HIP(hipGetLastError());
     return 0;
 }

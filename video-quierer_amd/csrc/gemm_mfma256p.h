@@ -271,6 +271,12 @@ static int launch_gemm_tn256p(hipStream_t st, const uint16_t* A, int lda, const 
 // workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 3 = ring,
 // 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles.  Auto picks the 160-row tiles when they put one workgroup on
 // more CUs than 256-row tiles would (VQ_AMD_GEMM160=0 disables that).
+static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one launch per GEMM
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_TAIL"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v != 0;
+}
+
 template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
@@ -282,6 +288,23 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
     if (fits256 && want256 && force == 4) return launch_gemm_tn256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (fits256 && want256 && force == 3) return launch_gemm_tn256_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (fits256 && want256 && force == 0 && allow160 && gemm_use_tail_split()) {
+        // Tile quantisation: T tiles over 256 CUs run ceil(T/256) rounds.  When the last round is less than half
+        // full, its tiles' rows go to the 128x128 kernel instead (4x the workgroups, two per CU: one short round)
+        // — same K order per output element, so the results are bit-identical.  Not for concurrent handles:
+        // other streams fill the idle CUs of a thin round.
+        const int tiles_n = N / G2_BN, tiles_m = M / G2_BM;
+        const int64_t tiles = (int64_t)tiles_m * tiles_n;
+        const int rem = (int)(tiles % 256);
+        if (tiles > 256 && rem > 0 && rem < 128) {
+            const int main_rows_tiles = (int)((tiles - rem) / tiles_n);          // whole tile rows inside the full rounds
+            const int m_main = main_rows_tiles * G2_BM;
+            if (m_main > 0 && m_main < M) {
+                VQ_TRY((launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, m_main, N, K, epi)));
+                return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
+            }
+        }
+    }
     if (fits256 && want256 && force != 1) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
