@@ -5,6 +5,8 @@ hand-written gfx950 HIP kernels (csrc/, include/vq_amd.h).
 Drop-in classes (same names/signatures as the reference):
   core.feature_extractor.FeatureExtractor / BatchProcessor / CachedFeatureExtractor
   indexes.hnsw.HNSWIndex / OptimizedHNSWIndex
+Also: overhaul_index.SimpleVideoIndex (the live path's brute-force index), preprocess.FramePreprocessor
+(Pillow-exact / cv2-style resize and the frame-quality filter on the GPU), text_encoder.TextEncoder.
 
 Importing this package does not touch the GPU or the shared library; the
 classes do, on construction, and raise if either is missing (no CPU path).
@@ -31,4 +33,8 @@ def __getattr__(name):  # lazy: keep `import video_quierer_amd` free of ctypes/G
         return getattr(_importlib.import_module("video_quierer_amd.core.feature_extractor"), name)
     if name in ("HNSWIndex", "OptimizedHNSWIndex"):
         return getattr(_importlib.import_module("video_quierer_amd.indexes.hnsw"), name)
+    if name == "FramePreprocessor":
+        return getattr(_importlib.import_module("video_quierer_amd.preprocess"), name)
+    if name == "SimpleVideoIndex":
+        return getattr(_importlib.import_module("video_quierer_amd.overhaul_index"), name)
     raise AttributeError(name)
