@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Encode latency per device pass for small batches (one handle, one stream), device-resident frames."""
 import sys, os, time
-import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_quierer_amd.encoder import VitEncoder

@@ -2,7 +2,6 @@
 """Times the GPU resize (device-resident frames) and the host path, per source size.
 usage: resample_probe.py [n]"""
 import sys, os, time
-import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_quierer_amd.preprocess import FramePreprocessor, BILINEAR, BICUBIC, clip_processor_geometry

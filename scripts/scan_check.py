@@ -11,7 +11,6 @@ allq = knn_oracle.normalize_rows(rng.standard_normal((300, 512)).astype(np.float
 for n, nq, k in ((16384, 256, 10), (20480, 256, 10), (20001, 256, 10), (20001, 130, 10), (18432, 17, 10), (24576, 300, 10)):
     idx = OptimizedHNSWIndex(dimension=512)
     idx.add_device  # noqa
-    import ctypes
     from video_quierer_amd import _lib
     _lib.check(_lib.load().vq_index_add(idx._h, _lib.fptr(allv[:n]), n, 0))
     idx._ids = list(range(n)); idx._row_of = {i: i for i in range(n)}; idx.element_count = n; idx.entry_point = 0

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """One fp16-scan search at N rows x Q queries (for rocprofv3).  usage: scan_probe.py [N] [Q] [reps]"""
 import os, sys
-import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex, MODE_FP16

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 from ctypes import POINTER, c_float, c_int32, c_void_p
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional
 
 import numpy as np
 
