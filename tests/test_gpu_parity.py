@@ -17,7 +17,7 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])    # 1 = 128x128, 2 = 256x256 four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 7])    # 1 = 128x128, 2 = 256x256 four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring, 7 = four-wave 256x256
 def test_gemm_mfma_integer_exact(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(0)
@@ -52,7 +52,7 @@ def test_gemm_auto_tail_split_is_exact(gpu_lib):
     assert np.array_equal(debug_gemm(ar, wr, kernel=0), debug_gemm(ar, wr, kernel=2))      # bit-identical to one 256x256 launch
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 7])
 def test_gemm_mfma_random(gpu_lib, kernel):
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(1)

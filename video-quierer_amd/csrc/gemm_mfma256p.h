@@ -22,6 +22,7 @@
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
 #include "gemm_mfma160.h"
+#include "gemm_mfma256w4.h"
 
 namespace vq {
 
@@ -269,7 +270,7 @@ static int launch_gemm_tn256p(hipStream_t st, const uint16_t* A, int lda, const 
 
 // Dispatch: the phased 256x256 kernel when the problem tiles by it and yields enough
 // workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 3 = ring,
-// 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles.  Auto picks the 160-row tiles when they put one workgroup on
+// 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles, 7 = four-wave 256x256.  Auto picks the 160-row tiles when they put one workgroup on
 // more CUs than 256-row tiles would (VQ_AMD_GEMM160=0 disables that).
 static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one launch per GEMM
     static int v = -1;
@@ -284,6 +285,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     if (force == 6) force = 0;
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
         return launch_gemm_tn160_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 7) return launch_gemm_tn256w4<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
     if (fits256 && want256 && force == 4) return launch_gemm_tn256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);

@@ -84,7 +84,7 @@ int vq_init(int device_ordinal) {
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C) {
     VQ_TRY(require_init());
     VQ_CHECK(A && W && C, "vq_debug_gemm: null argument");
-    const int use_f16 = flags & 1, force = (flags >> 1) & 7;    // force: 0 auto, 1 = 128x128, 2 = four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring
+    const int use_f16 = flags & 1, force = (flags >> 1) & 7;    // force: 0 auto, 1 = 128x128, 2 = four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring, 7 = four-wave 256x256
     std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
     for (size_t i = 0; i < a16.size(); ++i)
         a16[i] = use_f16 ? __builtin_bit_cast(uint16_t, (_Float16)A[i]) : f32_to_bf16_rne(A[i]);
@@ -151,6 +151,7 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
     auto once = [&]() {
         if (kernel == 3) return launch_gemm_tn256_ring_diag<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, diag);
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        if (kernel == 7) return launch_gemm_tn256w4<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 4) return launch_gemm_tn256p<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         return launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, nullptr, diag);
