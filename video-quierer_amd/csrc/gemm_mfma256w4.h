@@ -236,7 +236,6 @@ void gemm_tn256w4r_kernel(const uint16_t* __restrict__ A, int lda,
     //   sc (sub-tile p+2, loaded during step p-1) -> LDS;  sub-tile p+3 -> sn;  fragments of p+1 -> (an, wn)
     auto step = [&](int p, frag (&af)[8], frag (&wf)[8], frag (&an)[8], frag (&wn)[8], uint4 (&sc)[8], uint4 (&sn)[8])
         __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // sc has arrived
         barrier();                                            // sub-tile p+1 is complete in LDS; slot of p+2 is free
         const char* nbuf = smem + slot_of(p + 1) * G3_SLOT;
         const int wslot = slot_of(p + 2);
@@ -245,13 +244,14 @@ void gemm_tn256w4r_kernel(const uint16_t* __restrict__ A, int lda,
         for (int idx = 0; idx < 64; ++idx) {
             const int i = idx >> 3, j = idx & 7;
             mfma_agpr<IS_F16>(acc[j >> 2][i][j & 3], wf[j], af[i]);
-            if (idx < 16 && (idx & 1) == 0) sn[idx >> 1] = load_chunk(p + 3, idx >> 1);             // 8 global loads first: a whole step to land
-            if (idx >= 16 && idx < 32 && (idx & 1) == 0) write_chunk(wslot, (idx - 16) >> 1, sc[(idx - 16) >> 1]);   // 8 LDS writes
-            if (idx >= 32 && (idx & 1) == 1) {                                                          // 16 fragment reads
-                const int r = (idx - 32) >> 1;
+            if (idx < 16 && (idx & 1) == 0) sn[idx >> 1] = load_chunk(p + 3, idx >> 1);             // 8 global loads: 1.5 steps to land
+            if (idx < 32 && (idx & 1) == 1) {                                                       // 16 fragment reads, done well before the step ends
+                const int r = idx >> 1;
                 if (r < 8) an[r] = *(const frag*)(nbuf + a_base + r * 1024);
                 else       wn[r - 8] = *(const frag*)(nbuf + w_base + (r - 8) * 1024);
             }
+            if (idx >= 32 && idx < 48 && (idx & 1) == 0)                                            // 8 LDS writes of the sub-tile loaded a step ago
+                write_chunk(wslot, (idx - 32) >> 1, sc[(idx - 32) >> 1]);
         }
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
