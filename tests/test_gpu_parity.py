@@ -860,3 +860,25 @@ def test_ingest_recovers_after_a_bad_frame(gpu_lib):
     again = fx.extract_from_video_frames(fds)
     assert len(again) == 96 and np.abs(np.stack([o["features"] for o in again]) - fx.model.encode(np.stack(frames))).max() <= 2e-6
     fx.thread_pool.shutdown()
+
+
+def test_index_zero_vectors_do_not_break_search(gpu_lib):
+    """The reference divides by the norm without a guard (hnsw.py:157, :250/:499): a zero query yields NaN distances
+    and no error [SURVEY.md §8a K6], a zero row is stored as NaNs.  Here: a zero query returns k entries with NaN
+    distance/score and no exception on both scan paths; a zero row never displaces a finite result."""
+    import warnings
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    rng = np.random.default_rng(17)
+    for n in (100, 20000):                                   # exact path / fp16-scan path
+        vecs = rng.standard_normal((n, 64)).astype(np.float32)
+        idx = OptimizedHNSWIndex(dimension=64)
+        idx.add_batch(list(vecs), list(range(n)))
+        before = [(r["id"], r["distance"]) for r in idx.search(vecs[5], 5)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = idx.search(np.zeros(64, np.float32), 3)
+            assert len(res) == 3 and all(np.isnan(r["distance"]) and np.isnan(r["score"]) for r in res)
+            idx.add(np.zeros(64, np.float32), 10 * n)
+        assert idx.size() == n + 1
+        assert [(r["id"], r["distance"]) for r in idx.search(vecs[5], 5)] == before
+        idx.close()
