@@ -63,6 +63,9 @@ struct EpiBiasQuickGeluH16 {
 };
 
 // x += acc + bias   (fp32 residual stream)      (E5: out_proj / fc2 + residual)
+// SITE only names the call site (0 = out_proj, 1 = fc2): the two GEMMs then are distinct kernels in a
+// rocprofv3 --kernel-trace --stats summary instead of one line mixing 27-us and 80-us launches.
+template <int SITE>
 struct EpiBiasResidualF32 {
     float* x; int ldx; const float* bias;
     static constexpr bool kLoads = true;

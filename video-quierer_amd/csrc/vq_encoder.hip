@@ -253,7 +253,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         {
             Prof p(e, C_GEMM_OUT);
             VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
-                                            EpiBiasResidualF32{e->x, H, L.b_out}, e->gemm_force)));
+                                            EpiBiasResidualF32<0>{e->x, H, L.b_out}, e->gemm_force)));
         }
         {
             Prof p(e, C_LAYERNORM);
@@ -268,7 +268,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         {
             Prof p(e, C_GEMM_FC2);
             VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
-                                            EpiBiasResidualF32{e->x, H, L.b_fc2}, e->gemm_force)));
+                                            EpiBiasResidualF32<1>{e->x, H, L.b_fc2}, e->gemm_force)));
         }
     }
     {   // E8-E10
