@@ -70,6 +70,17 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
 /* Same with flags: VQ_ENC_FP16 = fp16 instead of bf16 GEMM operands (same MFMA rate, ~8x smaller
  * rounding error; the type ViT-L/14@336 is specified with).  $VQ_AMD_DTYPE=fp16|bf16 overrides. */
 #define VQ_ENC_FP16 1
+/* Operand type per GEMM group (set = fp16, clear = bf16; fp32 accumulation and the same MFMA rate either way):
+ * PATCH = pixels x W_patch, QKV = LN1 output x W_qkv, ATTN = q|k|v, softmax P, attention output x W_out,
+ * FC1 = LN2 output x W_fc1, FC2 = quick-GELU output x W_fc2.  VQ_ENC_MIXED is the build's default for
+ * ViT-B/32 (which roundings the 1e-3 score tolerance can afford).  $VQ_AMD_DTYPE =
+ * bf16 | fp16 | mixed | mask:<bits 0-4> overrides the flags. */
+#define VQ_ENC_F16_PATCH 0x100
+#define VQ_ENC_F16_QKV 0x200
+#define VQ_ENC_F16_ATTN 0x400
+#define VQ_ENC_F16_FC1 0x800
+#define VQ_ENC_F16_FC2 0x1000
+#define VQ_ENC_MIXED (VQ_ENC_F16_FC1 | VQ_ENC_F16_FC2)
 /* VQ_ENC_CONCURRENT: the caller keeps several encoder handles busy at once on separate HIP streams.  The
  * N = hidden GEMMs then keep 256-row tiles (150 dense workgroups at batch 256, leaving CUs to the other
  * streams: +7 % aggregate frames/s measured with 3 streams) instead of the 160-row tiles that spread one

@@ -106,14 +106,12 @@ def test_encoder_matches_golden_embeddings(encoder, golden_encoder):
     assert np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
     cos = np.sum(emb * golden_encoder["embeddings"], axis=1)
     assert cos.min() >= 1.0 - COS_TOL, f"min cosine vs transformers fp32 = {cos.min()}"
-    # cosine scores against arbitrary index rows: 64,000 pairs.  bf16 GEMM inputs give an embedding
-    # error of ~5e-3 in L2 (1-cos ~1.6e-5), i.e. a score error of rms ~2.4e-4 per pair; the extreme of
-    # 64k pairs sits at the 1e-3 tolerance, so the bound here is on the 99.99th percentile, and the
-    # scores of actual top-k results are checked against 1e-3 in test_config1_end_to_end.
+    # cosine scores against arbitrary index rows, all 64,000 pairs: the north star's "cosine scores within 1e-3"
     rows = knn_oracle.normalize_rows(np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32))
     diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
-    assert np.quantile(diff, 0.9999) <= COS_TOL and diff.max() <= 1.5 * COS_TOL
-    print(f"encoder vs golden: min cos {cos.min():.7f}, score diff rms {np.sqrt((diff**2).mean()):.2e} max {diff.max():.2e}")
+    print(f"encoder ({encoder.compute_dtype}) vs golden: min cos {cos.min():.7f}, "
+          f"score diff rms {np.sqrt((diff**2).mean()):.2e} max {diff.max():.2e}")
+    assert diff.max() <= COS_TOL
 
 
 def test_encoder_fp16_operands_are_8x_closer(gpu_lib, b32_weights, golden_encoder):
@@ -307,22 +305,59 @@ def test_config1_end_to_end(gpu_lib, encoder, golden_knn, golden_encoder):
     uq = np.stack([q / np.linalg.norm(q) for q in emb]).astype(np.float32)
     oid, od = knn_oracle.topk(golden_knn["stored"], uq, 5)
     assert np.array_equal(ids, oid)
-    # against the all-reference pipeline (transformers fp32 embeddings + exhaustive hnsw.py):
-    # scores within 1e-3; id lists identical wherever the reference's own gaps exceed the tolerance
+    # against the all-reference pipeline (transformers fp32 embeddings + exhaustive hnsw.py, hnsw.py:517-523
+    # score = 1 - distance): EVERY returned (id, score), at k = 5 and k = 10, is within 1e-3 of the reference
+    # pipeline's own score for that id; id lists are identical wherever the reference's gaps exceed the tolerance
+    ref_emb, stored = golden_encoder["embeddings"], golden_knn["stored"]
     ref_ids, ref_sc = golden_knn["ids_ef1000_k5"], golden_knn["score_ef1000_k5"]
     ref_d10 = golden_knn["dist_ef1000_k10"]
+    res10 = idx.search_batch(list(emb), 10)
+    worst = 0.0
+    for kk, rr_all in ((5, res), (10, res10)):
+        for i, rr in enumerate(rr_all):
+            assert len(rr) == kk
+            for r in rr:
+                ref_score = np.float32(1.0) - (np.float32(1.0) - np.float32(np.dot(stored[r["id"]], ref_emb[i])))
+                worst = max(worst, abs(float(r["score"]) - float(ref_score)))
+    assert worst <= COS_TOL, f"a returned score is {worst:.2e} away from the reference pipeline's score for the same id"
     same = 0
     for i in range(64):
-        gaps = np.diff(ref_d10[i][:6])
-        if gaps.min() > 2 * COS_TOL:
+        if np.diff(ref_d10[i][:6]).min() > 2 * COS_TOL:
             assert list(ids[i]) == list(ref_ids[i])
             assert np.abs(sc[i] - ref_sc[i]).max() <= COS_TOL
             same += 1
-        else:
-            assert set(ids[i]) <= set(golden_knn["ids_ef1000_k10"][i]) | set(ids[i])
+    # whatever differs from the reference's list is a near-tie: the reference's own score for the id this build
+    # returned is within 2e-3 of the reference's k-th score
+    for i in range(64):
+        kth = ref_sc[i][-1]
+        for j in ids[i]:
+            assert np.dot(stored[j], ref_emb[i]) >= kth - 2 * COS_TOL
     recall = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(ids, ref_ids)])
-    print(f"config1: {same}/64 queries gap-checked identical; recall@5 vs reference pipeline {recall:.4f}")
+    print(f"config1 ({encoder.compute_dtype}): worst |score - reference score| {worst:.2e} over 64x(5+10) results; "
+          f"{same}/64 queries gap-checked identical; recall@5 vs reference pipeline {recall:.4f}")
     assert recall >= 0.95
+
+
+def test_config1_recall_by_operand_type(gpu_lib, b32_weights, golden_knn, golden_encoder):
+    """recall@5 of the whole pipeline against the all-reference pipeline, per operand-type choice (printed for
+    DESIGN.md §2); every choice must keep every returned score within 1e-3 except plain bf16, which is the
+    measured reason the default is not plain bf16."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    vecs = np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32)
+    idx = _mk_index(vecs)
+    rows = golden_knn["stored"]
+    for dt in ("bf16", "mixed", "fp16"):
+        enc = VitEncoder(VIT_B_32, b32_weights, max_batch=64, compute_dtype=dt)
+        emb = enc.encode(synth_frames(64))
+        enc.close()
+        ids = np.array([[r["id"] for r in rr] for rr in idx.search_batch(list(emb), 5)])
+        recall = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(ids, golden_knn["ids_ef1000_k5"])])
+        diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
+        print(f"operands {dt:5s}: recall@5 vs reference pipeline {recall:.4f}, max score diff {diff.max():.2e}")
+        if dt != "bf16":
+            assert diff.max() <= COS_TOL
+    idx.close()
 
 
 # ------------------------------------------------------------------ fp16 MFMA scan + exact re-score
@@ -822,8 +857,15 @@ def test_pipelined_ingest_matches_single_pass(gpu_lib):
     fx = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=16)      # 16-frame passes -> many passes
     frames = list(synth_frames(150, seed=31))
     fds = [{"frame": f, "frame_number": i} for i, f in enumerate(frames)]
+    import time as _t
+    t0 = _t.time()
     out = fx.extract_from_video_frames(fds)                                           # 10 passes: both ingest handles
+    wall = _t.time() - t0
     assert [o["frame_number"] for o in out] == list(range(150))
+    # get_stats (reference :236-258) multiplies the number of extraction_times entries by batch_size: one entry per
+    # reference-sized batch, so the figure is frames / seconds (19 entries x 8 = 152 ~ 150 frames)
+    st = fx.get_stats()
+    assert len(fx.extraction_times) == 19 and 0.8 * 150 / wall <= st["throughput_images_per_sec"]
     ref = fx.model.encode(np.stack(frames[:150]))
     got = np.stack([o["features"] for o in out])
     assert np.abs(got - ref).max() <= 2e-6            # different tile shapes (160- vs 256-row GEMM tiles): fp32 summation order only

@@ -14,9 +14,9 @@ What differs from the reference, deliberately:
 * Frames that are not 224x224 are resized on the GPU, bit-identically to Pillow (preprocess.py);
   ``resize_mode="clip_processor"`` selects the live path's short-edge-bicubic + centre-crop instead of the
   reference class's stretch.
-* GEMMs run in bf16 with fp32 accumulation; embeddings agree with the fp32
-  reference to cosine >= 1 - 1e-3 (tests/test_gpu_parity.py); ``compute_dtype="fp16"``
-  switches the operands to fp16 (8x smaller error, same speed).
+* GEMMs take 16-bit operands with fp32 accumulation: ``compute_dtype="mixed"`` (default: bf16 attention
+  GEMMs, fp16 MLP GEMMs), ``"bf16"``, ``"fp16"`` or ``"fp16:<group>+…"`` (encoder.py); every cosine score
+  agrees with the fp32 reference within 1e-3 at the default (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ from typing import Any, Dict, List, Sequence, Union
 
 import numpy as np
 
-from video_quierer_amd.encoder import VitEncoder
+from video_quierer_amd.encoder import DEFAULT_COMPUTE_DTYPE, VitEncoder
 from video_quierer_amd.preprocess import BICUBIC, BILINEAR, FramePreprocessor, clip_processor_geometry
 from video_quierer_amd.weights import resolve_model
 
@@ -60,7 +60,7 @@ class FeatureExtractor:
 
     def __init__(self, model_name: str = "openai/clip-vit-base-patch32", device: str = "auto",
                  batch_size: int = 32, num_threads: int = 4, cache_model: bool = True,
-                 device_batch: int = 256, compute_dtype: str = "bf16", resize_mode: str = "stretch",
+                 device_batch: int = 256, compute_dtype: str = DEFAULT_COMPUTE_DTYPE, resize_mode: str = "stretch",
                  ingest_streams: int = 2):
         if resize_mode not in ("stretch", "clip_processor"):
             raise ValueError("resize_mode must be 'stretch' (the reference's Resize((S,S))) or 'clip_processor'")
@@ -72,7 +72,7 @@ class FeatureExtractor:
         self.batch_size = batch_size
         self.num_threads = num_threads
         self.cache_model = cache_model
-        self.compute_dtype = compute_dtype          # GEMM operand type on the GPU: "bf16" (default) or "fp16"
+        self.compute_dtype = compute_dtype          # GEMM operand types on the GPU (encoder.dtype_to_flags)
         # frames per device pass; extract_from_video_frames groups up to this many
         self.device_batch = max(int(device_batch), int(batch_size))
 
@@ -264,21 +264,28 @@ class FeatureExtractor:
                 if ci >= depth:
                     collect(ci - depth)
                     collected += 1
-                    self.extraction_times.append(time.time() - t0)
-                    t0 = time.time()
+                    t0 = self._account_pass(len(chunks[ci - depth]), t0)
                 stage(ci)
                 staged += 1
             while collected < len(chunks):
                 collect(collected)
                 collected += 1
-                self.extraction_times.append(time.time() - t0)
-                t0 = time.time()
+                t0 = self._account_pass(len(chunks[collected - 1]), t0)
         finally:
             for ci in range(collected, staged):      # an error left passes in flight: drain their slots for the next ingest
                 try:
                     models[ci % nm].wait_staged((ci // nm) & 1, len(chunks[ci]))
                 except Exception:
                     pass
+
+    def _account_pass(self, n_frames: int, t0: float) -> float:
+        """One device pass covers several reference-sized batches: book it as that many ``extraction_times``
+        entries (reference :163-165 appends one per ``batch_size`` batch and get_stats multiplies the entry count
+        by ``batch_size``, :246-250), so ``throughput_images_per_sec`` stays frames / seconds."""
+        now = time.time()
+        nb = max(1, -(-n_frames // self.batch_size))
+        self.extraction_times.extend([(now - t0) / nb] * nb)
+        return now
 
     def extract_from_video_frames(self, frames_data: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         """Reference :179-209.  Frames are independent, so several ``batch_size`` slices are encoded in one

@@ -285,11 +285,18 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     if (force == 6) force = 0;
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
         return launch_gemm_tn160_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#ifdef VQ_GEMM_EXPERIMENTS
     if (force == 7) return launch_gemm_tn256w4<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#else
+    if (force == 3 || force == 4 || force == 7)
+        return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
+#endif
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
+#ifdef VQ_GEMM_EXPERIMENTS
     if (fits256 && want256 && force == 4) return launch_gemm_tn256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (fits256 && want256 && force == 3) return launch_gemm_tn256_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#endif
     if (fits256 && want256 && force == 0 && allow160 && gemm_use_tail_split()) {
         // Tile quantisation: T tiles over 256 CUs run ceil(T/256) rounds.  When the last round is less than half
         // full, its tiles' rows go to the 128x128 kernel instead (4x the workgroups, two per CU: one short round)

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <thread>
 #include <vector>
 
@@ -75,7 +76,8 @@ struct vq_encoder {
     float* tok_emb = nullptr; int* d_ids = nullptr; int* d_rowidx = nullptr; int vocab = 0, eos_id = 0;
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
-    bool fp16 = false;       // GEMM operand type: bf16 (default, the BASELINE config) or fp16 ($VQ_AMD_DTYPE / create flag)
+    int f16_mask = 0;        // per-GEMM-group operand type, DT_* bits (set = fp16, clear = bf16): create flags / $VQ_AMD_DTYPE
+    bool h_is_f16 = false;   // type of what `h` holds right now (debug_read)
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles, 6 = auto without 160-row tiles
     // profiling
     bool profiling = false;
@@ -132,13 +134,29 @@ int upload_h16(uint16_t* dst, const float* src, size_t n, bool f16, float scale 
     return 0;
 }
 
-template <int NV, bool F16>
+// Operand type per GEMM group (bit set = fp16, clear = bf16; fp32 accumulation either way, same MFMA rate).
+// A group = every 16-bit tensor that meets in one MFMA: the weights and the activations that multiply them.
+//   DT_PATCH  patch pixels (exact in both types) x W_patch
+//   DT_QKV    LN1 output h x W_qkv
+//   DT_ATTN   q | k | v, softmax probabilities, attention output x W_out
+//   DT_FC1    LN2 output h x W_fc1
+//   DT_FC2    quick-GELU output x W_fc2
+enum : int { DT_PATCH = 1, DT_QKV = 2, DT_ATTN = 4, DT_FC1 = 8, DT_FC2 = 16, DT_ALL = 31 };
+
+template <class Fn> static inline int by_f16(bool f16, Fn&& fn) {
+    return f16 ? fn(std::true_type{}) : fn(std::false_type{});
+}
+#define VQ_F16(tag) (decltype(tag)::value)
+
+template <int NV>
 int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16,
                 const int* d_ids = nullptr) {
     const vq_vit_config& c = e->cfg;
     hipStream_t st = e->stream;
     const int H = c.hidden, T = e->tokens;
     const int rows = n * T;
+    const bool fP = e->f16_mask & DT_PATCH, fQ = e->f16_mask & DT_QKV, fA = e->f16_mask & DT_ATTN,
+               f1 = e->f16_mask & DT_FC1, f2 = e->f16_mask & DT_FC2;
     // GEMM row counts are padded (the buffers are): to 256 when that adds < 6 % work, so the phased
     // 256x256 kernel applies; small batches keep 128-row granularity
     auto pad_rows = [](int r) {
@@ -153,73 +171,100 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     };
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
+    auto layernorm = [&](bool f16, const float* x, uint16_t* h, const float* g, const float* b, int nrows, int stride) {
+        return by_f16(f16, [&](auto F) {
+            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, VQ_F16(F)>), dim3(cdiv(nrows, 4)), dim3(256), 0, st, x, h, g, b, nrows,
+                               c.ln_eps, stride);
+            return 0;
+        });
+    };
 
     const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
     if (e->is_text) {
         Prof p(e, C_EMBED_FINISH);
         const LayerW& L0 = e->layers[0];
-        hipLaunchKernelGGL((embed_tokens_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, d_ids, e->tok_emb, e->pos,
-                           e->x, e->h, L0.ln1_g, L0.ln1_b, rows, T, e->vocab, c.ln_eps);
+        by_f16(fQ, [&](auto F) {
+            hipLaunchKernelGGL((embed_tokens_kernel<NV, VQ_F16(F)>), dim3(cdiv(rows, 4)), dim3(256), 0, st, d_ids, e->tok_emb,
+                               e->pos, e->x, e->h, L0.ln1_g, L0.ln1_b, rows, T, e->vocab, c.ln_eps);
+            return 0;
+        });
         hipLaunchKernelGGL(eos_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_ids, e->d_rowidx, n, T, e->eos_id);
     } else {
     {   // E1/E2 + im2col: uint8 frames -> 16-bit patch rows (aliases the MLP buffer)
         Prof p(e, C_PATCHIFY);
-        if (c.patch_size % 8 == 0 && e->patch_k == 3 * c.patch_size * c.patch_size) {
-            const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
-            const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL(patchify_u8_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
-                               c.image_size, c.patch_size, swap_rb);
-        } else {
-            const int64_t total = (int64_t)n * e->patches * 3 * c.patch_size;
-            const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL(patchify_generic_kernel<F16>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
-                               c.image_size, c.patch_size, e->patch_k, swap_rb);
-        }
+        by_f16(fP, [&](auto F) {
+            if (c.patch_size % 8 == 0 && e->patch_k == 3 * c.patch_size * c.patch_size) {
+                const int64_t total = (int64_t)n * c.image_size * (c.image_size / 8);
+                const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+                hipLaunchKernelGGL(patchify_u8_kernel<VQ_F16(F)>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+                                   c.image_size, c.patch_size, swap_rb);
+            } else {
+                const int64_t total = (int64_t)n * e->patches * 3 * c.patch_size;
+                const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+                hipLaunchKernelGGL(patchify_generic_kernel<VQ_F16(F)>, dim3(blocks), dim3(256), 0, st, d_frames, e->mlp, n,
+                                   c.image_size, c.patch_size, e->patch_k, swap_rb);
+            }
+            return 0;
+        });
     }
     {   // E3: patch-embedding conv as a GEMM, epilogue scatters into token rows + position embedding
         Prof p(e, C_GEMM_PATCH);
-        VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
-                                        EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force)));
+        VQ_TRY(by_f16(fP, [&](auto F) {
+            return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
+                                               EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force);
+        }));
     }
     {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
         Prof p(e, C_EMBED_FINISH);
         const LayerW& L0 = e->layers[0];
-        hipLaunchKernelGGL((embed_finish_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
-                           e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
+        by_f16(fQ, [&](auto F) {
+            hipLaunchKernelGGL((embed_finish_kernel<NV, VQ_F16(F)>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
+                               e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
+            return 0;
+        });
     }
     }
+    e->h_is_f16 = fQ;
     for (int l = 0; l < nl; ++l) {
         const LayerW& L = e->layers[l];
         if (l > 0) {
             Prof p(e, C_LAYERNORM);
-            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
-                               L.ln1_g, L.ln1_b, rows, c.ln_eps);
+            layernorm(fQ, e->x, e->h, L.ln1_g, L.ln1_b, rows, 1);
+            e->h_is_f16 = fQ;
         }
         {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
             Prof p(e, C_GEMM_QKV);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_qkv, H, gemm_rows(3 * H, H), 3 * H, H,
-                                            EpiBiasH16<F16>{e->qkv, 3 * H, L.b_qkv}, e->gemm_force)));
+            VQ_TRY(by_f16(fQ, [&](auto F) {
+                return by_f16(fA, [&](auto FO) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_qkv, H, gemm_rows(3 * H, H), 3 * H, H,
+                                                       EpiBiasH16<VQ_F16(FO)>{e->qkv, 3 * H, L.b_qkv}, e->gemm_force);
+                });
+            }));
         }
         {
             Prof p(e, C_ATTENTION);
-            if (e->is_text) {
-                const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
-                hipLaunchKernelGGL((attention_stream_wg_kernel<F16, true>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
-                                   e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
-            } else if (T <= 64 && c.heads % 4 == 0) {
-                hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
-                                   c.heads);
-            } else {
-                const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
-                if (e->attn_simple) {
-                    const int units = n * c.heads * q_tiles;
-                    hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
-                                       e->att, T, H, c.heads, q_tiles, units);
-                } else {
-                    hipLaunchKernelGGL((attention_stream_wg_kernel<F16, false>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
+            by_f16(fA, [&](auto F) {
+                constexpr bool F16 = VQ_F16(F);
+                if (e->is_text) {
+                    const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
+                    hipLaunchKernelGGL((attention_stream_wg_kernel<F16, true>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
                                        e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
+                } else if (T <= 64 && c.heads % 4 == 0) {
+                    hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
+                                       c.heads);
+                } else {
+                    const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
+                    if (e->attn_simple) {
+                        const int units = n * c.heads * q_tiles;
+                        hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
+                                           e->att, T, H, c.heads, q_tiles, units);
+                    } else {
+                        hipLaunchKernelGGL((attention_stream_wg_kernel<F16, false>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
+                                           e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
+                    }
                 }
-            }
+                return 0;
+            });
         }
         // Only the CLS token of the last block is consumed (E8): its out_proj / LN2 / MLP run on the
         // n CLS rows instead of n*T rows (292.8 MMAC of 4408.8 per frame).  K/V and the
@@ -230,45 +275,61 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
             {
                 Prof p(e, C_GEMM_OUT);
                 hipLaunchKernelGGL(gather_rows_h16_kernel, dim3(cdiv(n * (H / 8), 256)), dim3(256), 0, st, e->att, e->h, n, H, T);
-                VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_out, H, crows, H, H,
-                                              EpiBiasResidualClsF32{e->x, H, T, L.b_out, n}, e->gemm_force)));
+                e->h_is_f16 = fA;
+                VQ_TRY(by_f16(fA, [&](auto F) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_out, H, crows, H, H,
+                                                       EpiBiasResidualClsF32{e->x, H, T, L.b_out, n}, e->gemm_force);
+                }));
             }
             {
                 Prof p(e, C_LAYERNORM);
-                hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(n, 4)), dim3(256), 0, st, e->x, e->att,
-                                   L.ln2_g, L.ln2_b, n, c.ln_eps, T);
+                layernorm(f1, e->x, e->att, L.ln2_g, L.ln2_b, n, T);
             }
             {
                 Prof p(e, C_GEMM_FC1);
-                VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_fc1, H, crows, c.mlp, H,
-                                              EpiBiasQuickGeluH16<F16>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
+                VQ_TRY(by_f16(f1, [&](auto F) {
+                    return by_f16(f2, [&](auto FO) {
+                        return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_fc1, H, crows, c.mlp, H,
+                                                           EpiBiasQuickGeluH16<VQ_F16(FO)>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force);
+                    });
+                }));
             }
             {
                 Prof p(e, C_GEMM_FC2);
-                VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp,
-                                              EpiBiasResidualClsF32{e->x, H, T, L.b_fc2, n}, e->gemm_force)));
+                VQ_TRY(by_f16(f2, [&](auto F) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp,
+                                                       EpiBiasResidualClsF32{e->x, H, T, L.b_fc2, n}, e->gemm_force);
+                }));
             }
             continue;
         }
         {
             Prof p(e, C_GEMM_OUT);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
-                                            EpiBiasResidualF32<0>{e->x, H, L.b_out}, e->gemm_force)));
+            VQ_TRY(by_f16(fA, [&](auto F) {
+                return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
+                                                   EpiBiasResidualF32<0>{e->x, H, L.b_out}, e->gemm_force);
+            }));
         }
         {
             Prof p(e, C_LAYERNORM);
-            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h,
-                               L.ln2_g, L.ln2_b, rows, c.ln_eps);
+            layernorm(f1, e->x, e->h, L.ln2_g, L.ln2_b, rows, 1);
+            e->h_is_f16 = f1;
         }
         {   // E7: fc1 + quick_gelu
             Prof p(e, C_GEMM_FC1);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->h, H, L.w_fc1, H, gemm_rows(c.mlp, H), c.mlp, H,
-                                            EpiBiasQuickGeluH16<F16>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force)));
+            VQ_TRY(by_f16(f1, [&](auto F) {
+                return by_f16(f2, [&](auto FO) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_fc1, H, gemm_rows(c.mlp, H), c.mlp, H,
+                                                       EpiBiasQuickGeluH16<VQ_F16(FO)>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force);
+                });
+            }));
         }
         {
             Prof p(e, C_GEMM_FC2);
-            VQ_TRY((launch_gemm_auto<F16>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
-                                            EpiBiasResidualF32<1>{e->x, H, L.b_fc2}, e->gemm_force)));
+            VQ_TRY(by_f16(f2, [&](auto F) {
+                return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
+                                                   EpiBiasResidualF32<1>{e->x, H, L.b_fc2}, e->gemm_force);
+            }));
         }
     }
     {   // E8-E10
@@ -285,16 +346,25 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
 
 int forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, float* d_out_f32, uint16_t* d_out_f16,
             const int* d_ids = nullptr) {
-    const int key = (e->cfg.hidden / 256) * 2 + (e->fp16 ? 1 : 0);
-    switch (key) {
-        case 4: return run_forward<2, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
-        case 5: return run_forward<2, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
-        case 6: return run_forward<3, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
-        case 7: return run_forward<3, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
-        case 8: return run_forward<4, false>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
-        case 9: return run_forward<4, true>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+    switch (e->cfg.hidden / 256) {
+        case 2: return run_forward<2>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 3: return run_forward<3>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
+        case 4: return run_forward<4>(e, d_frames, n, swap_rb, d_out_f32, d_out_f16, d_ids);
         default: return fail(VQ_ERR_INVALID, "unsupported hidden size %d", e->cfg.hidden);
     }
+}
+
+// create flags / $VQ_AMD_DTYPE -> DT_* mask.  VQ_ENC_FP16: every group; VQ_ENC_F16_* bits: that group.
+// $VQ_AMD_DTYPE = bf16 | fp16 | mixed | mask:<int> overrides the flags (experiments, bench.py --dtype).
+int dtype_mask_from(int flags) {
+    int mask = (flags & VQ_ENC_FP16) ? DT_ALL : ((flags >> 8) & DT_ALL);
+    if (const char* dt = getenv("VQ_AMD_DTYPE")) {
+        if (!strcmp(dt, "fp16") || !strcmp(dt, "f16")) mask = DT_ALL;
+        else if (!strcmp(dt, "bf16")) mask = 0;
+        else if (!strcmp(dt, "mixed")) mask = (VQ_ENC_MIXED >> 8) & DT_ALL;
+        else if (!strncmp(dt, "mask:", 5)) mask = atoi(dt + 5) & DT_ALL;
+    }
+    return mask;
 }
 
 }  // namespace
@@ -330,8 +400,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     if (const char* at = getenv("VQ_AMD_ATTN")) e->attn_simple = !strcmp(at, "simple");
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
-    e->fp16 = (flags & VQ_ENC_FP16) != 0;
-    if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
+    e->f16_mask = dtype_mask_from(flags);
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
     e->rows_pad = round_up((int64_t)max_batch * tokens + (G5_BM - 1), 256);     // room for 256- and 160-row padding
     e->prow_pad = round_up((int64_t)max_batch * patches, 256);
@@ -367,7 +436,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
             for (int ch = 0; ch < 3; ++ch)
                 for (int i = 0; i < pp; ++i) {
                     const double w = wp[(n * 3 + ch) * pp + i];
-                    w16[n * patch_k + ch * pp + i] = e->fp16 ? __builtin_bit_cast(uint16_t, (_Float16)(float)(w / (255.0 * stdv[ch])))
+                    w16[n * patch_k + ch * pp + i] = (e->f16_mask & DT_PATCH) ? __builtin_bit_cast(uint16_t, (_Float16)(float)(w / (255.0 * stdv[ch])))
                                                              : f32_to_bf16_rne((float)(w / (255.0 * stdv[ch])));
                     b += w * (128.0 / 255.0 - mean[ch]) / stdv[ch];
                 }
@@ -391,18 +460,18 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
         L.b_qkv = A.take<float>(3 * H);
         for (int part = 0; part < 3; ++part) {        // q, k, v
             const float s = part == 0 ? qscale : 1.0f;
-            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->fp16, s));
+            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->f16_mask & DT_QKV, s));
             std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
             for (auto& v : b) v *= s;
             UP(upload_f32(L.b_qkv + part * H, b.data(), H));
         }
-        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->fp16));
+        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->f16_mask & DT_ATTN));
         L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
         L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
         L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
-        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->fp16));
+        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->f16_mask & DT_FC1));
         L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
-        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->fp16));
+        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
         L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
     }
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));
@@ -451,8 +520,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
-    e->fp16 = (flags & VQ_ENC_FP16) != 0;
-    if (const char* dt = getenv("VQ_AMD_DTYPE")) e->fp16 = !strcmp(dt, "fp16") || !strcmp(dt, "f16");
+    e->f16_mask = dtype_mask_from(flags);
     auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
 
     const size_t H = t.hidden, M = t.mlp, T = e->tokens;
@@ -493,18 +561,18 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
         L.b_qkv = A.take<float>(3 * H);
         for (int part = 0; part < 3; ++part) {
             const float sc = part == 0 ? qscale : 1.0f;
-            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->fp16, sc));
+            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->f16_mask & DT_QKV, sc));
             std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
             for (auto& v : b) v *= sc;
             UP(upload_f32(L.b_qkv + part * H, b.data(), H));
         }
-        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->fp16));
+        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->f16_mask & DT_ATTN));
         L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
         L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
         L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
-        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->fp16));
+        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->f16_mask & DT_FC1));
         L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
-        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->fp16));
+        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
         L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
     }
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));     // final_layer_norm
@@ -770,16 +838,16 @@ int vq_encoder_debug_read(vq_encoder* e, const char* name, int rows, float* out)
         VQ_HIP(hipMemcpy(out, e->x, (size_t)rows * H * 4, hipMemcpyDeviceToHost));
         return 0;
     }
-    const uint16_t* src = nullptr; size_t cols = 0;
-    if (!strcmp(name, "h")) { src = e->h; cols = H; }
-    else if (!strcmp(name, "qkv")) { src = e->qkv; cols = 3 * H; }
-    else if (!strcmp(name, "att")) { src = e->att; cols = H; }
-    else if (!strcmp(name, "mlp")) { src = e->mlp; cols = e->cfg.mlp; }
+    const uint16_t* src = nullptr; size_t cols = 0; bool f16 = false;
+    if (!strcmp(name, "h")) { src = e->h; cols = H; f16 = e->h_is_f16; }
+    else if (!strcmp(name, "qkv")) { src = e->qkv; cols = 3 * H; f16 = e->f16_mask & DT_ATTN; }
+    else if (!strcmp(name, "att")) { src = e->att; cols = H; f16 = e->f16_mask & DT_ATTN; }
+    else if (!strcmp(name, "mlp")) { src = e->mlp; cols = e->cfg.mlp; f16 = e->f16_mask & DT_FC2; }
     else return fail(VQ_ERR_INVALID, "vq_encoder_debug_read: unknown buffer '%s'", name);
     std::vector<uint16_t> tmp((size_t)rows * cols);
     VQ_HIP(hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i)
-        out[i] = e->fp16 ? (float)__builtin_bit_cast(_Float16, tmp[i]) : bf16_to_f32(tmp[i]);
+        out[i] = f16 ? (float)__builtin_bit_cast(_Float16, tmp[i]) : bf16_to_f32(tmp[i]);
     return 0;
 }
 

@@ -14,13 +14,35 @@ from . import _lib
 from .weights import VitConfig, weight_names
 
 
+# GEMM operand type per group (include/vq_amd.h VQ_ENC_F16_*): fp32 accumulation and the same MFMA rate either way
+DTYPE_GROUPS = {"patch": 0x100, "qkv": 0x200, "attn": 0x400, "fc1": 0x800, "fc2": 0x1000}
+MIXED_FP16_GROUPS = ("fc1", "fc2")          # = VQ_ENC_MIXED
+DEFAULT_COMPUTE_DTYPE = "mixed"             # plain bf16 operands miss the 1e-3 score tolerance
+
+
+def dtype_to_flags(compute_dtype: str) -> int:
+    """'bf16' | 'fp16' | 'mixed' (bf16 with MIXED_FP16_GROUPS in fp16) | 'fp16:<group>+<group>…' (named groups in
+    fp16, the rest bf16)."""
+    if compute_dtype == "bf16":
+        return 0
+    if compute_dtype == "fp16":
+        return 1
+    if compute_dtype == "mixed":
+        return sum(DTYPE_GROUPS[g] for g in MIXED_FP16_GROUPS)
+    if compute_dtype.startswith("fp16:"):
+        try:
+            return sum(DTYPE_GROUPS[g] for g in compute_dtype[5:].split("+") if g)
+        except KeyError as e:
+            raise ValueError(f"unknown GEMM group {e} (have {sorted(DTYPE_GROUPS)})") from None
+    raise ValueError("compute_dtype must be 'bf16', 'fp16', 'mixed' or 'fp16:<group>+…'")
+
+
 class VitEncoder:
     def __init__(self, cfg: VitConfig, weights: Dict[str, np.ndarray], max_batch: int = 256,
-                 device: Optional[int] = None, compute_dtype: str = "bf16", concurrent: bool = False):
+                 device: Optional[int] = None, compute_dtype: str = DEFAULT_COMPUTE_DTYPE, concurrent: bool = False):
         """concurrent: several handles are kept busy on separate streams (VQ_ENC_CONCURRENT in vq_amd.h)."""
-        if compute_dtype not in ("bf16", "fp16"):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
         self.compute_dtype = compute_dtype
+        dtype_flags = dtype_to_flags(compute_dtype)
         self.cfg = cfg
         self.max_batch = int(max_batch)
         self.device = _lib.init(device)
@@ -32,7 +54,7 @@ class VitEncoder:
                                cfg.proj_dim, cfg.ln_eps)
         h = c_void_p()
         _lib.check(lib.vq_encoder_create_ex(ctypes.byref(ccfg), ptrs, len(names), self.max_batch,
-                                            (1 if compute_dtype == "fp16" else 0) | (2 if concurrent else 0),
+                                            dtype_flags | (2 if concurrent else 0),
                                             ctypes.byref(h)))
         self._h = h
         self._keep = None          # the library has its own device copies now

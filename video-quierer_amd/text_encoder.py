@@ -13,14 +13,15 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _lib
+from .encoder import DEFAULT_COMPUTE_DTYPE, dtype_to_flags
 from .weights import TextConfig, text_weight_shapes
 
 
 class TextEncoder:
     def __init__(self, cfg: TextConfig, weights: Dict[str, np.ndarray], max_batch: int = 64,
-                 device: Optional[int] = None, compute_dtype: str = "bf16"):
-        if compute_dtype not in ("bf16", "fp16"):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
+                 device: Optional[int] = None, compute_dtype: str = DEFAULT_COMPUTE_DTYPE):
+        dtype_flags = dtype_to_flags(compute_dtype)
+        self.compute_dtype = compute_dtype
         self.cfg = cfg
         self.device = _lib.init(device)
         lib = _lib.load()
@@ -31,7 +32,7 @@ class TextEncoder:
                                 cfg.proj_dim, cfg.eos_token_id, cfg.ln_eps)
         h = c_void_p()
         _lib.check(lib.vq_text_encoder_create(ctypes.byref(ccfg), ptrs, len(names), int(max_batch),
-                                              1 if compute_dtype == "fp16" else 0, ctypes.byref(h)))
+                                              dtype_flags, ctypes.byref(h)))
         self._h = h
         self.output_dim = cfg.proj_dim
 
