@@ -186,7 +186,10 @@ int vq_index_destroy(vq_index* idx);
 /* add / add_batch (hnsw.py:150-236): appends n rows.  normalize=1 divides each
  * row by its L2 norm on the device (fixed-order fp64 chain, see oracle/knn_oracle.c);
  * normalize=0 stores the rows as given (the Python wrapper normalises with numpy
- * exactly like the reference, hnsw.py:157, and passes 0). */
+ * exactly like the reference, hnsw.py:157, and passes 0).  Rows stored as given are MEASURED, not trusted:
+ * the index keeps the range of |row|^2 it holds; while 0.5 <= |row|^2 <= 2 the fp16 scan stays available
+ * with its error bound scaled by the largest |row|, outside that range mode 0 uses the exact scan and
+ * mode 2 is refused. */
 int vq_index_add(vq_index* idx, const float* rows, int64_t n, int normalize);
 int vq_index_add_device(vq_index* idx, const void* d_rows_f32, int64_t n, int normalize);
 int vq_index_size(vq_index* idx, int64_t* n);
@@ -194,8 +197,8 @@ int vq_index_clear(vq_index* idx);
 
 /* search / search_batch (hnsw.py:238-300, 488-528) as an exact scan:
  *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row).
- * queries [nq][dim] must already be L2-normalised (the wrapper does query /
- * ||query|| with numpy, hnsw.py:250).  ids/dist are [nq][k]; unused slots
+ * queries [nq][dim] are used as given (the wrapper does query / ||query|| with numpy, hnsw.py:250); the
+ * fp16 path's exactness bound scales with each query's own norm, so un-normalised queries stay exact.  ids/dist are [nq][k]; unused slots
  * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 32), 1 exact
  * fp32-master scan, 2 fp16 MFMA scan + exact re-score with proof (unproven queries are redone by the
  * exact scan).  The fp16 path reads its per-query outcome flags back, so vq_index_search_device returns

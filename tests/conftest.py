@@ -74,3 +74,57 @@ def resample_input(h, w, kind, seed=RESAMPLE_SEED):
 @pytest.fixture(scope="session")
 def golden_resample():
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample_pil.npz"))
+
+
+# ---- a local HF-style checkpoint directory (the only non-seeded way in: feature_extractor.py:76-77) ----
+TOY_MERGES = [("c", "a"), ("ca", "t</w>"), ("d", "o"), ("do", "g</w>"), ("t", "h"), ("th", "e</w>")]
+
+
+def toy_text_config():
+    """Text tower sized for the toy tokenizer below (520 tokens: 256 byte symbols, their end-of-word forms, six
+    merges, <|startoftext|> = 518, <|endoftext|> = 519); everything else is CLIP ViT-B/32's text geometry."""
+    from video_quierer_amd.weights import TextConfig
+    return TextConfig(vocab=520, eos_token_id=519, bos_token_id=518)
+
+
+def write_checkpoint_dir(path, seed=WEIGHT_SEED, dtype="float32"):
+    """model.safetensors (both towers, HF state_dict names, plus the extra tensors a real CLIP checkpoint carries) +
+    config.json + vocab.json / merges.txt of a byte-level BPE the transformers CLIPTokenizer accepts."""
+    import json
+    from video_quierer_amd.weights import VIT_B_32, seeded_text_weights, seeded_weights
+    os.makedirs(path, exist_ok=True)
+    tensors = dict(seeded_weights(VIT_B_32, seed))
+    tensors.update(seeded_text_weights(toy_text_config(), seed))
+    tensors["logit_scale"] = np.array(4.6052, dtype=np.float32)                        # ignored by the loader
+    tensors["vision_model.embeddings.position_ids"] = np.arange(50, dtype=np.int64)[None]
+    if dtype == "float32":
+        from safetensors.numpy import save_file
+        save_file(tensors, os.path.join(path, "model.safetensors"))
+    else:
+        import torch
+        from safetensors.torch import save_file
+        td = getattr(torch, dtype)
+        save_file({k: (torch.from_numpy(v).to(td) if v.dtype == np.float32 else torch.from_numpy(v)) for k, v in tensors.items()},
+                  os.path.join(path, "model.safetensors"))
+    cfg = {"model_type": "clip", "projection_dim": 512,
+           "vision_config": {"image_size": 224, "patch_size": 32, "hidden_size": 768, "intermediate_size": 3072,
+                             "num_hidden_layers": 12, "num_attention_heads": 12, "layer_norm_eps": 1e-5},
+           "text_config": {"vocab_size": 520, "max_position_embeddings": 77, "hidden_size": 512, "intermediate_size": 2048,
+                           "num_hidden_layers": 12, "num_attention_heads": 8, "eos_token_id": 519, "bos_token_id": 518,
+                           "layer_norm_eps": 1e-5}}
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    chars = [chr(c) for c in cs]
+    vocab = chars + [c + "</w>" for c in chars] + [a + b for a, b in TOY_MERGES] + ["<|startoftext|>", "<|endoftext|>"]
+    with open(os.path.join(path, "vocab.json"), "w") as f:
+        json.dump({t: i for i, t in enumerate(vocab)}, f)
+    with open(os.path.join(path, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in TOY_MERGES) + "\n")
+    return path

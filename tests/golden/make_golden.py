@@ -17,6 +17,9 @@ Produces
   resample_pil.npz           (`make_golden.py resample`) Pillow's resize / transformers' CLIP image processor on
                              seeded frames: two full outputs + SHA-256 of all eight (inputs are regenerated
                              from the seed by resample_input()).
+  ref_index_50.pkl(.sha256), ref_index_50_results.npz, simple_index.npz, ref_simple_index_cache.pkl
+                             (`make_golden.py interop`) files WRITTEN by the real reference classes and the result
+                             lists the real classes return (persistence / live-index fixtures).
   knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
                              OptimizedHNSWIndex, random.seed(0)) over 1,000
                              seeded vectors: its levels, entry point and graph,
@@ -206,7 +209,86 @@ def capture_knn(queries):
     np.savez_compressed(os.path.join(HERE, "knn_cfg1.npz"), **out)
 
 
+INTEROP_SEED, INTEROP_N = 11, 50
+
+
+def interop_vectors():
+    """50 seeded rows (dim 64) and 8 queries for the persistence fixtures; ids are the strings the reference's
+    caller builds (video_search_system.py:164-166)."""
+    rng = np.random.default_rng(INTEROP_SEED)
+    vecs = (rng.standard_normal((INTEROP_N, 64)) * 2.5).astype(np.float32)
+    ids = [f"video{i // 25}_{i % 25}" for i in range(INTEROP_N)]
+    qs = rng.standard_normal((8, 64)).astype(np.float32)
+    return vecs, ids, qs
+
+
+def capture_interop():
+    """(i) A file written by the REAL reference HNSWIndex.save (hnsw.py:306-339) + the result lists the real class
+    returns from it (ef_search 50 >= N: exhaustive) — the build must load that file and reproduce the lists.
+    (ii) The REAL SimpleVideoIndex (video_search_overhaul.py:23-64): the module itself cannot be imported (cv2 is
+    not installed: ordinary ImportError), but the class needs only numpy, so its ClassDef is lifted out of the
+    reference source with `ast` and executed here; its outputs on seeded rows (un-normalised rows, exact
+    duplicates) are the fixture."""
+    import ast
+    import logging
+    import pickle
+    from pathlib import Path
+    from typing import Any, Dict, List, Optional, Union
+    sys.path.insert(0, "/root/reference/src")
+    from indexes.hnsw import HNSWIndex                 # the real reference
+
+    vecs, ids, qs = interop_vectors()
+    random.seed(3)
+    idx = HNSWIndex(dimension=64)
+    idx.add_batch(list(vecs), ids)
+    path = os.path.join(HERE, "ref_index_50.pkl")
+    idx.save(path)
+    fresh = HNSWIndex(dimension=64)
+    fresh.load(path)
+    res = [fresh.search(q, 5) for q in qs]
+    np.savez_compressed(os.path.join(HERE, "ref_index_50_results.npz"),
+                        ids=np.array([[r["id"] for r in rr] for rr in res]),
+                        dist=np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32),
+                        score=np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32),
+                        seed=INTEROP_SEED)
+
+    src = open("/root/reference/video_search_overhaul.py").read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "SimpleVideoIndex")
+    ns = dict(np=np, pickle=pickle, Path=Path, List=List, Dict=Dict, Any=Any, Optional=Optional, Union=Union,
+              logger=logging.getLogger("golden"))
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "video_search_overhaul.py", "exec"), ns)
+    SimpleVideoIndex = ns["SimpleVideoIndex"]
+    rng = np.random.default_rng(77)
+    emb = rng.standard_normal((300, 512)).astype(np.float32)
+    emb[:200] /= np.linalg.norm(emb[:200], axis=1, keepdims=True)      # the last 100 rows stay un-normalised
+    emb[250] = emb[230]                                                  # exact duplicates -> ties
+    emb[20] = emb[10]
+    sv = SimpleVideoIndex()
+    assert sv.search(emb[0], 3) == []
+    for i, e in enumerate(emb):
+        sv.add_frame(e, f"video_{i // 100}.mp4", i * 0.5)
+    qidx = [0, 7, 10, 123, 230, 260]
+    out = {"query_rows": np.array(qidx), "query_scale": np.float32(2.5)}
+    for k in (1, 5, 12):
+        res = [sv.search(emb[qi] * np.float32(2.5), k) for qi in qidx]
+        out[f"frame_id_k{k}"] = np.array([[r["frame_id"] for r in rr] for rr in res], dtype=np.int32)
+        out[f"score_k{k}"] = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float64)
+        out[f"timestamp_k{k}"] = np.array([[r["timestamp"] for r in rr] for rr in res], dtype=np.float64)
+    out["keys"] = np.array(sorted(res[0][0].keys()))
+    cache = os.path.join(HERE, "ref_simple_index_cache.pkl")
+    small = SimpleVideoIndex()
+    for i in range(12):
+        small.add_frame(emb[i], f"clip_{i // 6}.mp4", i * 0.25)
+    small.video_hashes = {"clip_0.mp4": "abc", "clip_1.mp4": "def"}
+    assert small.save_to_disk(Path(cache))
+    out["cache_frame_id_k3"] = np.array([r["frame_id"] for r in small.search(emb[5], 3)], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "simple_index.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "interop" in sys.argv[1:]:
+        capture_interop()
+        sys.exit(0)
     if "l14" in sys.argv[1:]:
         capture_encoder_l14()
         sys.exit(0)

@@ -407,33 +407,117 @@ def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
 
 
 # ------------------------------------------------------------------ live system's brute-force index ("next" #2)
-def test_simple_video_index_matches_reference_semantics(gpu_lib, tmp_path):
+def test_simple_video_index_matches_the_real_class(gpu_lib, tmp_path):
+    """tests/golden/simple_index.npz holds what the REAL SimpleVideoIndex (video_search_overhaul.py:23-64, lifted out
+    of the reference source by make_golden.py) returns on these seeded rows: 100 un-normalised rows, two pairs of
+    exact duplicates, queries scaled by 2.5.  Frame ids identical (ties included), scores within fp32 rounding."""
     from video_quierer_amd.overhaul_index import SimpleVideoIndex
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simple_index.npz"))
     rng = np.random.default_rng(77)
     emb = rng.standard_normal((300, 512)).astype(np.float32)
     emb[:200] /= np.linalg.norm(emb[:200], axis=1, keepdims=True)      # the last 100 rows stay un-normalised
-    emb[250] = emb[230]                                                  # exact duplicate → tie
+    emb[250] = emb[230]
+    emb[20] = emb[10]
     idx = SimpleVideoIndex()
     assert idx.search(emb[0], 3) == []
     for i, e in enumerate(emb):
         idx.add_frame(e, f"video_{i // 100}.mp4", i * 0.5)
-    for qi in (0, 7, 123, 230, 260):
-        q = emb[qi] * 2.5
-        got = idx.search(q, 5)
-        # restatement of video_search_overhaul.py:40-64
-        sims = emb @ (q / (np.linalg.norm(q) + 1e-10))
-        want = np.argsort(sims, kind="stable")[::-1][:5]
-        assert [g["frame_id"] for g in got] == [int(w) for w in want]
-        assert np.allclose([g["score"] for g in got], sims[want], atol=2e-6)
-        assert set(got[0]) == {"video_name", "timestamp", "frame_id", "score"} and isinstance(got[0]["score"], float)
-    assert [g["frame_id"] for g in idx.search(emb[230], 2)] == [250, 230]  # tie → larger frame id first
+    for k in (1, 5, 12):
+        for row, qi in enumerate(gold["query_rows"]):
+            got = idx.search(emb[qi] * np.float32(gold["query_scale"]), k)
+            assert [g["frame_id"] for g in got] == list(gold[f"frame_id_k{k}"][row]), (k, qi)
+            ref_sc = gold[f"score_k{k}"][row]
+            assert np.abs(np.array([g["score"] for g in got]) - ref_sc).max() <= 4e-6 * max(1.0, np.abs(ref_sc).max())
+            assert [g["timestamp"] for g in got] == list(gold[f"timestamp_k{k}"][row])
+            assert sorted(got[0]) == list(gold["keys"]) and isinstance(got[0]["score"], float)
+    # a cache file written by the real class loads here and answers like the real class did
+    fresh = SimpleVideoIndex()
+    assert fresh.load_from_disk(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_simple_index_cache.pkl"))
+    assert fresh.video_hashes == {"clip_0.mp4": "abc", "clip_1.mp4": "def"} and len(fresh.embeddings) == 12
+    assert [g["frame_id"] for g in fresh.search(emb[5], 3)] == list(gold["cache_frame_id_k3"])
     path = tmp_path / "cache.pkl"
     assert idx.save_to_disk(path)
-    fresh = SimpleVideoIndex()
-    assert fresh.load_from_disk(path) and not fresh.load_from_disk(tmp_path / "missing.pkl")
-    assert [g["frame_id"] for g in fresh.search(emb[123], 5)] == [g["frame_id"] for g in idx.search(emb[123], 5)]
+    again = SimpleVideoIndex()
+    assert again.load_from_disk(path) and not again.load_from_disk(tmp_path / "missing.pkl")
+    assert [g["frame_id"] for g in again.search(emb[123], 5)] == [g["frame_id"] for g in idx.search(emb[123], 5)]
+    with open(path, "rb") as f:
+        assert sorted(pickle.load(f)) == ["embeddings", "metadata", "version", "video_hashes"]     # reference layout :68-73
     idx.add_frame(emb[123] * 3, "late.mp4", 1.0)                         # incremental add after a search
     assert idx.search(emb[123], 1)[0]["frame_id"] == 300
+
+
+# ------------------------------------------------------------------ persistence interop (K10)
+def _interop_vectors():
+    rng = np.random.default_rng(11)                                      # make_golden.py interop_vectors()
+    vecs = (rng.standard_normal((50, 64)) * 2.5).astype(np.float32)
+    ids = [f"video{i // 25}_{i % 25}" for i in range(50)]
+    qs = rng.standard_normal((8, 64)).astype(np.float32)
+    return vecs, ids, qs
+
+
+def test_index_loads_a_file_written_by_the_reference(gpu_lib):
+    """tests/golden/ref_index_50.pkl(.sha256) was written by the REAL HNSWIndex.save (hnsw.py:306-339); the result
+    lists next to it are what the real class returns after loading it (ef_search 50 >= N: exhaustive)."""
+    from video_quierer_amd.indexes.hnsw import HNSWIndex
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = np.load(os.path.join(gdir, "ref_index_50_results.npz"))
+    vecs, ids, qs = _interop_vectors()
+    idx = HNSWIndex(dimension=512)                                       # load() adopts the file's dimension (64)
+    idx.load(os.path.join(gdir, "ref_index_50.pkl"))
+    assert idx.dimension == 64 and idx.size() == 50 and idx.M == 16 and idx.ef_search == 50
+    assert idx.entry_point in ids and set(idx.data) == set(ids)
+    for i, q in enumerate(qs):
+        res = idx.search(q, 5)
+        assert [r["id"] for r in res] == list(gold["ids"][i])
+        assert np.abs(np.array([r["distance"] for r in res]) - gold["dist"][i]).max() <= 3e-7
+        assert np.abs(np.array([r["score"] for r in res]) - gold["score"][i]).max() <= 3e-7
+    assert [[r["id"] for r in rr] for rr in idx.search_batch(list(qs), 5)] == [list(r) for r in gold["ids"]]
+    idx.close()
+
+
+def test_index_save_writes_the_reference_layout(gpu_lib, tmp_path):
+    """The other direction: the file this build writes.  tests/test_oracle_golden.py loads the committed copy
+    (tests/golden/build_index_50.pkl, written by this test with VQ_WRITE_FIXTURES=1 on the GPU box) with the REAL
+    class in the build container."""
+    from video_quierer_amd.indexes.hnsw import HNSWIndex
+    vecs, ids, qs = _interop_vectors()
+    idx = HNSWIndex(dimension=64)
+    idx.add_batch(list(vecs), ids)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out") \
+        if os.environ.get("VQ_WRITE_FIXTURES") == "1" else str(tmp_path)
+    path = os.path.join(out_dir, "build_index_50.pkl")
+    idx.save(path)
+    with open(path, "rb") as f:
+        s = pickle.load(f)
+    assert {"dimension", "M", "max_M", "ef_construction", "ef_search", "level_generation_factor", "data", "levels",
+            "graph", "entry_point", "element_count"} <= set(s)                # hnsw.py:311-324
+    stored = np.stack([s["data"][i] for i in ids])
+    assert np.array_equal(stored, np.stack([v / np.linalg.norm(v) for v in vecs]).astype(np.float32))   # hnsw.py:157
+    idx.close()
+
+
+# ------------------------------------------------------------------ the real-checkpoint door
+def test_feature_extractor_from_a_local_checkpoint_directory(gpu_lib, tmp_path):
+    """FeatureExtractor(model_name=<local HF directory>) (reference :76-81 from_pretrained): embeddings bit-identical
+    to the seeded model carrying the same tensors; extract_text_features runs the checkpoint's own tokenizer
+    (reference :218-234) and equals the ids path and the fp32 oracle."""
+    from conftest import toy_text_config, write_checkpoint_dir
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    from video_quierer_amd.weights import seeded_text_weights
+    d = write_checkpoint_dir(str(tmp_path / "clip-vit-base-patch32"))
+    fx = FeatureExtractor(model_name=d, batch_size=8, device_batch=8)
+    ref = FeatureExtractor(model_name="seed:1234", batch_size=8, device_batch=8)
+    frames = list(synth_frames(8, seed=17))
+    assert fx.output_dim == 512 and fx.model_name == d
+    assert np.array_equal(fx.extract_batch(frames), ref.extract_batch(frames))
+    t = fx.extract_text_features("the cat")
+    assert t.shape == (512,) and t.dtype == np.float32 and abs(float(np.linalg.norm(t)) - 1.0) < 1e-5
+    ids = np.array([[518, 517, 513, 519]])
+    assert np.array_equal(t, fx.extract_text_features_from_ids(ids[0]))
+    want = clip_vit_oracle.encode_token_ids(ids, seeded_text_weights(toy_text_config(), 1234), eos_token_id=519)[0]
+    assert float(np.dot(t, want)) >= 1.0 - 1e-4
+    assert float(np.dot(fx.extract_text_features("a dog sat"), t)) < 0.999        # a different prompt, a different vector
+    fx.thread_pool.shutdown(); ref.thread_pool.shutdown()
 
 
 # ------------------------------------------------------------------ threading / wrappers / odd sizes

@@ -102,3 +102,48 @@ def test_clip_processor_geometry_matches_the_restatement():
         assert clip_processor_geometry(h, w) == resample_oracle.clip_processor_geometry(h, w), (h, w)
     with pytest.raises(ValueError):
         clip_processor_geometry(0, 10)
+
+
+def test_local_checkpoint_directory_loads(tmp_path):
+    """The real-checkpoint door (reference feature_extractor.py:76-81 `from_pretrained(name)`; here: a LOCAL HF
+    directory, never a fetch): safetensors + config.json + tokenizer files in, the same tensors out."""
+    from conftest import toy_text_config, write_checkpoint_dir
+    from video_quierer_amd.text_encoder import load_tokenizer
+    from video_quierer_amd.weights import (VIT_B_32, resolve_model, resolve_text_model, seeded_text_weights,
+                                            seeded_weights)
+    d = write_checkpoint_dir(str(tmp_path / "clip-vit-base-patch32"))
+    cfg, w = resolve_model(d)
+    want = seeded_weights(VIT_B_32, 1234)
+    assert cfg == VIT_B_32 and set(w) == set(want)
+    assert all(w[k].dtype == np.float32 and np.array_equal(w[k], want[k]) for k in want)
+    tcfg, tw, tok_dir = resolve_text_model(d)
+    twant = seeded_text_weights(toy_text_config(), 1234)
+    assert tcfg == toy_text_config() and tok_dir == d and set(tw) == set(twant)
+    assert all(np.array_equal(tw[k], twant[k]) for k in twant)
+    tok = load_tokenizer(d)
+    assert tok is not None
+    ids = tok(["the cat", "a dog sat"], padding=True, truncation=True, max_length=77)["input_ids"]
+    assert ids[0] == [518, 517, 513, 519, 519, 519, 519] and ids[1][0] == 518 and ids[1][-1] == 519
+    # a hub NAME resolves only through $VQ_AMD_MODEL_DIR/<basename>
+    os.environ["VQ_AMD_MODEL_DIR"] = str(tmp_path)
+    try:
+        cfg2, w2 = resolve_model("openai/clip-vit-base-patch32")
+    finally:
+        del os.environ["VQ_AMD_MODEL_DIR"]
+    assert cfg2 == VIT_B_32 and np.array_equal(w2["visual_projection.weight"], want["visual_projection.weight"])
+    # 16-bit checkpoints are widened on load
+    import torch
+    d16 = write_checkpoint_dir(str(tmp_path / "bf16"), dtype="bfloat16")
+    _, w16 = resolve_model(d16)
+    k = "vision_model.encoder.layers.3.mlp.fc1.weight"
+    assert np.array_equal(w16[k], torch.from_numpy(want[k]).bfloat16().float().numpy())
+    # broken directories fail loudly
+    os.remove(os.path.join(d16, "model.safetensors"))
+    with pytest.raises(FileNotFoundError):
+        resolve_model(d16)
+    from safetensors.numpy import save_file
+    part = {k_: v for k_, v in want.items() if "layers.11" not in k_}
+    save_file(part, os.path.join(d16, "model.safetensors"))
+    with pytest.raises(KeyError):
+        resolve_model(d16)
+    assert load_tokenizer(str(tmp_path / "nowhere")) is None

@@ -188,3 +188,82 @@ def test_cv_resize_oracle_properties():
     assert np.abs(up.astype(int) - ro.resize_u8(img, 224, 224, ro.BILINEAR)).max() <= 1
     s, w0, w1 = cv.linear_coeffs(1920, 224, True)
     assert np.all(w0 + w1 == 2048) and s.min() >= 0 and s.max() <= 1919 and np.all(np.diff(s) > 0)
+
+
+# ---- persistence / live-index fixtures written by the REAL reference classes (make_golden.py interop) ----
+def _golden(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+def _interop_vectors():
+    rng = np.random.default_rng(11)
+    vecs = (rng.standard_normal((50, 64)) * 2.5).astype(np.float32)
+    ids = [f"video{i // 25}_{i % 25}" for i in range(50)]
+    qs = rng.standard_normal((8, 64)).astype(np.float32)
+    return vecs, ids, qs
+
+
+def test_reference_written_index_file_equals_exact_oracle():
+    """The pickle the real HNSWIndex.save wrote: its keys (hnsw.py:311-324), its sidecar, its rows (= v/|v|, :157)
+    and the result lists the real class returned from it = the exact oracle's answer in (distance, id) order."""
+    import pickle
+    with open(_golden("ref_index_50.pkl"), "rb") as f:
+        raw = f.read()
+    assert hashlib.sha256(raw).hexdigest() == open(_golden("ref_index_50.pkl.sha256")).read().strip()
+    s = pickle.loads(raw)
+    assert sorted(s) == sorted(["dimension", "M", "max_M", "ef_construction", "ef_search", "level_generation_factor",
+                                "data", "levels", "graph", "entry_point", "element_count"])
+    vecs, ids, qs = _interop_vectors()
+    stored = np.stack([s["data"][i] for i in ids])
+    assert np.array_equal(stored, np.stack([v / np.linalg.norm(v) for v in vecs]).astype(np.float32))
+    gold = np.load(_golden("ref_index_50_results.npz"))
+    uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    rows, dist = knn_oracle.topk(stored, uq, 5)
+    assert [[ids[r] for r in rr] for rr in rows] == [list(r) for r in gold["ids"]]
+    assert np.abs(dist - gold["dist"]).max() <= 3e-7
+
+
+def test_reference_class_loads_a_build_written_index_file():
+    """Build-container only (needs /root/reference): the file the GPU build's HNSWIndex.save wrote
+    (tests/golden/build_index_50.pkl, produced on the GPU box by tests/test_gpu_parity.py::
+    test_index_save_writes_the_reference_layout) loads with the REAL class — same rows, same ids, same parameters.
+    It carries no navigable graph: searching it with the reference needs a re-add, shown here."""
+    import os
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/src") or not os.path.exists(_golden("build_index_50.pkl")):
+        pytest.skip("needs /root/reference and the committed build-written file")
+    sys.path.insert(0, "/root/reference/src")
+    try:
+        from indexes.hnsw import HNSWIndex
+    finally:
+        sys.path.remove("/root/reference/src")
+    vecs, ids, qs = _interop_vectors()
+    ref = HNSWIndex(dimension=8)
+    ref.load(_golden("build_index_50.pkl"))
+    assert ref.dimension == 64 and ref.size() == 50 and ref.entry_point in ids
+    assert np.array_equal(np.stack([ref.data[i] for i in ids]), np.stack([v / np.linalg.norm(v) for v in vecs]).astype(np.float32))
+    assert len(ref.search(qs[0], 5)) == 1          # flat graph: the reference's walk sees the entry point only
+    random.seed(3)
+    rebuilt = HNSWIndex(dimension=64)
+    rebuilt.add_batch([ref.data[i] for i in ids], ids)
+    gold = np.load(_golden("ref_index_50_results.npz"))
+    assert [[r["id"] for r in rebuilt.search(q, 5)] for q in qs] == [list(r) for r in gold["ids"]]
+
+
+def test_simple_index_fixture_is_reversed_argsort_of_dots():
+    """What the real SimpleVideoIndex returned (simple_index.npz) restated: top-k of E @ (q / (|q| + 1e-10)) by
+    np.argsort(sim)[::-1] (video_search_overhaul.py:49-57); exact duplicates come out larger frame id first."""
+    gold = np.load(_golden("simple_index.npz"))
+    rng = np.random.default_rng(77)
+    emb = rng.standard_normal((300, 512)).astype(np.float32)
+    emb[:200] /= np.linalg.norm(emb[:200], axis=1, keepdims=True)
+    emb[250] = emb[230]
+    emb[20] = emb[10]
+    for row, qi in enumerate(gold["query_rows"]):
+        q = emb[qi] * np.float32(gold["query_scale"])
+        sims = emb @ (q / (np.linalg.norm(q) + 1e-10))
+        assert list(np.argsort(sims)[::-1][:12]) == list(gold["frame_id_k12"][row])
+        assert np.allclose(sims[gold["frame_id_k12"][row]], gold["score_k12"][row], rtol=0, atol=1e-5)
+    assert list(gold["frame_id_k5"][4][:2]) == [250, 230]

@@ -99,9 +99,17 @@ _device = None
 
 
 def build(force: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into lib/libvq_amd.so (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else [])
-    subprocess.check_call(cmd)
+    """Compile csrc/*.hip for gfx950 into lib/libvq_amd.so (hipcc cross-compiles without a GPU).  Serialised by
+    a file lock: under torch.distributed.run every rank may find the library missing at the same moment; the
+    Makefile links to a temporary name and renames, so a concurrent dlopen never sees a half-written file."""
+    import fcntl
+    with open(os.path.join(CSRC_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not os.path.exists(LIB_PATH):
+                subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else []))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -141,7 +149,10 @@ def init(device: int | None = None) -> int:
     lib = load()
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) if _device is None else _device
-    if _device != device:
+    if _device is not None and _device != device:
+        raise VqError(f"this process is bound to GPU {_device}; one process drives one GPU "
+                      f"(asked for {device}): launch one rank per GPU")
+    if _device is None:
         check(lib.vq_init(int(device)))
         _device = device
     return _device

@@ -52,6 +52,36 @@ void normalize_rows_kernel(float* __restrict__ rows, int64_t n, int dim) {
     }
 }
 
+// ---- |row|^2 range of rows added WITHOUT normalisation (vq_index_add(normalize=0), HNSWIndex.load) ----
+// The fp16 scan's error bound is stated for near-unit rows (knn_scan_f16.h scan_eps_unit): the index tracks the
+// smallest and largest |row|^2 it holds and leaves the fp16 path when they stray.  One wave per row; the positive
+// fp32 bit patterns order like the values, so atomicMin/atomicMax on the bits keep the range.
+__global__ __launch_bounds__(256)
+void row_norm_range_kernel(const float* __restrict__ rows, int64_t n, int dim, uint32_t* __restrict__ range /*[2]: min, max bits*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.f;
+    for (int i = lane * 4; i < dim; i += 256) {
+        const float4 v = *(const float4*)(rows + r * dim + i);
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (!(s >= 0.f) || s > 3.0e38f) s = 3.0e38f;          // NaN / inf rows: out of any acceptable range
+        const uint32_t b = __builtin_bit_cast(uint32_t, s);
+        atomicMin(range, b);
+        atomicMax(range + 1, b);
+    }
+}
+
+// empty index on the device API: every slot is "no candidate" (hnsw.py:243-244 returns [])
+__global__ void fill_no_result_kernel(int32_t* __restrict__ ids, float* __restrict__ dist, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { ids[i] = -1; dist[i] = __builtin_inff(); }
+}
+
 // fp32 master -> fp16 scan copy (round-to-nearest-even)
 __global__ __launch_bounds__(256)
 void rows_to_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t count4) {

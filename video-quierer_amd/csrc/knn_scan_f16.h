@@ -37,8 +37,16 @@ namespace vq {
 constexpr int SCAN_QT = 128;          // queries per workgroup
 constexpr int SCAN_RANGE = 1024;      // matrix rows per workgroup (8 tiles of 128)
 constexpr int SCAN_STREAM_ROWS = 128; // rows seen by one lane stream
-constexpr float SCAN_EPS = 1.1e-3f;   // >= 2*2^-11 (fp16 rounding of both operands, Cauchy-Schwarz on unit
-                                      //    vectors) + fp32 accumulation (512*2^-24) + key packing (2^-16)
+// Worst-case |fp16 score - exact score| for a UNIT row and a UNIT query of dimension dim; it scales with |row||q|:
+//   2*2^-11 + 2^-22   fp16 rounding of both operands (Cauchy-Schwarz)
+//   dim * 2^-23       fp32 accumulation of the exact products, any order, truncating adders allowed
+//   2^-16             index bits packed into the low mantissa bits of the key
+//   2 * sqrt(dim) * 2^-25   elements below the fp16 normal range (absolute, not relative, rounding)
+// plus 2 % for the fp32 arithmetic that evaluates the bound itself.  1.07e-3 at dim 512, 1.5e-3 at dim 4096.
+static inline float scan_eps_unit(int dim) {
+    const double e = 2.0 / 2048 + 1.0 / 4194304 + dim / 8388608.0 + 1.0 / 65536 + 2.0 * __builtin_sqrt((double)dim) / 33554432.0;
+    return (float)(e * 1.02);
+}
 
 // row number of (stream, local index)
 __host__ __device__ inline int64_t scan_row_of(int64_t stream, int local) {
@@ -415,7 +423,8 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                            const float* __restrict__ rows, int64_t n_valid, int dim,
                            const float* __restrict__ queries, int nq, int k,
                            int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
-                           int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2 streams*/) {
+                           int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2 streams*/,
+                           float eps_rows /* scan_eps_unit(dim) x the largest |row| in the index */) {
     __shared__ float kept_v[RV_QPW][RV_SHARES * RV_KEEP];      // kept key values (with packed index bits)
     __shared__ int kept_s[RV_QPW][RV_SHARES * RV_KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
     __shared__ float share_floor[RV_QPW][RV_SHARES];           // upper bound of what a share dropped
@@ -428,6 +437,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     __shared__ int resc_stream[RV_QPW][RV_RESCAN_MAX];
     __shared__ int resc_n[RV_QPW];
     __shared__ int state[RV_QPW];
+    __shared__ float qn2[RV_QPW][RV_SHARES];                   // partial |q|^2 (the bound scales with |q|)
 
     const int tid = threadIdx.x;
     const int ql = tid & 15, share = tid >> 4;
@@ -497,6 +507,11 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     // ---- 3. exact re-score of the candidates: thread (query, c) for c = share, share+16 ----
     const bool q_live = q < nq;
     const float* qv = queries + (size_t)(q_live ? q : 0) * dim;
+    {
+        float s2 = 0.f;
+        for (int i = share; i < dim; i += RV_SHARES) s2 += qv[i] * qv[i];
+        qn2[ql][share] = s2;
+    }
     for (int c = share; c < RV_C; c += RV_SHARES) {
         const int src = cand_src[ql][c];
         int row = -1; float d = __builtin_inff();
@@ -527,6 +542,9 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             }
         }
         const float sk = 1.0f - dk;                            // k-th best exact score (−inf if fewer than k rows exist)
+        float q2 = 0.f;
+        for (int sh = 0; sh < RV_SHARES; ++sh) q2 += qn2[qq][sh];
+        const float SCAN_EPS = eps_rows * sqrtf(q2);           // NaN for a non-finite query: every test below fails -> exact fallback
         int st = 0;
         const bool all_rows_scored = n_valid <= 0;
         (void)all_rows_scored;

@@ -71,6 +71,9 @@ int vq_init(int device_ordinal) {
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     }
     VQ_CHECK(device_ordinal >= 0 && device_ordinal < n, "vq_init: device %d out of range [0,%d)", device_ordinal, n);
+    // one process = one GPU (one rank per GPU): kernel attributes and handles are set up for the bound device only
+    VQ_CHECK(g_device < 0 || g_device == device_ordinal, "vq_init: this process is already bound to device %d; "
+             "use one process per GPU (torch.distributed.run / bench.py --gpus N)", g_device);
     VQ_HIP(hipSetDevice(device_ordinal));
     hipDeviceProp_t prop;
     VQ_HIP(hipGetDeviceProperties(&prop, device_ordinal));

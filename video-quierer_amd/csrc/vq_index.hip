@@ -42,6 +42,11 @@ struct vq_index {
     int32_t* d_fb_ids = nullptr; int64_t fbi_cap = 0;
     float* d_fb_dist = nullptr; int64_t fbd_cap = 0;
     int64_t stats[3] = {0, 0, 0};
+    // |row|^2 range of rows added without normalisation (device: min/max fp32 bits); read back lazily by the first
+    // search after such an add.  near_unit = the fp16 scan's error bound applies (knn_scan_f16.h scan_eps_unit).
+    uint32_t* d_norm_range = nullptr;
+    bool norm_dirty = false, near_unit = true;
+    float row_norm_max = 1.0f;
     int scan_version = 2;          // $VQ_AMD_SCAN: 2 = 256x256 phased mainloop (needs dim % 128 == 0), 1 = 128x128
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -96,9 +101,20 @@ template <class T> int reserve_buf(T*& p, int64_t& cap, int64_t need) {
 // rows already on the device at x->rows + size*dim
 int finish_add(vq_index* x, int64_t n, int normalize) {
     float* dst = x->rows + x->size * x->dim;
-    if (normalize) {
+    {
         Prof p(x, I_NORMALIZE);
-        hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, NORM_ROWS)), dim3(NORM_ROWS), 0, x->stream, dst, n, x->dim);
+        if (normalize) {
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(n, NORM_ROWS)), dim3(NORM_ROWS), 0, x->stream, dst, n, x->dim);
+        } else {          // the caller says the rows are unit (HNSWIndex.load, SimpleVideoIndex): measure instead of trusting
+            if (!x->d_norm_range) {
+                VQ_HIP(hipMalloc((void**)&x->d_norm_range, 8));
+                const uint32_t init[2] = {0x3f800000u, 0x3f800000u};            // 1.0f, 1.0f
+                VQ_HIP(hipMemcpyAsync(x->d_norm_range, init, 8, hipMemcpyHostToDevice, x->stream));
+                VQ_HIP(hipStreamSynchronize(x->stream));                         // `init` is on this stack frame
+            }
+            hipLaunchKernelGGL(row_norm_range_kernel, dim3(cdiv(n, 4)), dim3(256), 0, x->stream, dst, n, x->dim, x->d_norm_range);
+            x->norm_dirty = true;
+        }
     }
     {
         Prof p(x, I_TO_F16);
@@ -195,7 +211,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             Prof p(x, I_RESCORE);
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                               d_dist_out + q0 * k, x->d_flags + q0, ver);
+                               d_dist_out + q0 * k, x->d_flags + q0, ver, scan_eps_unit(x->dim) * x->row_norm_max);
         }
     }
     VQ_HIP(hipGetLastError());
@@ -230,8 +246,18 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 
 int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
     VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
-    const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_C && x->size >= 1;
-    if (mode == 2) VQ_CHECK(fp16_ok, "vq_index_search: fp16 scan needs dim %% 64 == 0 and k <= %d", RV_C);
+    if (x->norm_dirty && mode != 1) {          // rows were added un-normalised since the last look: is the matrix still near-unit?
+        uint32_t range[2];
+        VQ_HIP(hipMemcpyAsync(range, x->d_norm_range, 8, hipMemcpyDeviceToHost, x->stream));
+        VQ_HIP(hipStreamSynchronize(x->stream));
+        const float lo = __builtin_bit_cast(float, range[0]), hi = __builtin_bit_cast(float, range[1]);
+        x->near_unit = lo >= 0.5f && hi <= 2.0f;
+        x->row_norm_max = hi > 1.0f ? sqrtf(hi) * 1.0001f : 1.0001f;
+        x->norm_dirty = false;
+    }
+    const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_C && x->size >= 1 && x->near_unit;
+    if (mode == 2) VQ_CHECK(fp16_ok, "vq_index_search: fp16 scan needs dim %% 64 == 0, k <= %d and near-unit rows "
+                                     "(0.5 <= |row|^2 <= 2; rows added with normalize=0 are measured)", RV_C);
     // auto: the MFMA scan pays once the matrix is large enough to amortise its fixed costs
     const bool use_fp16 = mode == 2 || (mode == 0 && fp16_ok && x->size >= 16384);
     return use_fp16 ? search_fp16(x, d_queries, nq, k, d_ids, d_dist) : search_exact(x, d_queries, nq, k, d_ids, d_dist);
@@ -266,6 +292,7 @@ int vq_index_destroy(vq_index* x) {
     (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
     (void)hipFree(x->d_fbq); (void)hipFree(x->d_fb_ids); (void)hipFree(x->d_fb_dist);
     if (x->h_flags) (void)hipHostFree(x->h_flags);
+    (void)hipFree(x->d_norm_range);
     delete x;
     return 0;
 }
@@ -280,6 +307,12 @@ int vq_index_clear(vq_index* x) {
     VQ_CHECK(x, "vq_index_clear: null handle");
     std::lock_guard<std::mutex> lk(x->mu);
     x->size = 0;
+    if (x->d_norm_range) {
+        const uint32_t init[2] = {0x3f800000u, 0x3f800000u};
+        VQ_HIP(hipMemcpyAsync(x->d_norm_range, init, 8, hipMemcpyHostToDevice, x->stream));
+        VQ_HIP(hipStreamSynchronize(x->stream));
+    }
+    x->norm_dirty = false; x->near_unit = true; x->row_norm_max = 1.0f;
     return 0;
 }
 
@@ -312,6 +345,12 @@ int vq_index_search_device(vq_index* x, const void* d_queries, int nq, int k, in
     VQ_CHECK(x && nq >= 0 && k > 0 && k <= 1024 && (nq == 0 || (d_queries && d_ids && d_dist)), "vq_index_search_device: bad argument");
     if (nq == 0) return 0;
     std::lock_guard<std::mutex> lk(x->mu);
+    if (x->size == 0) {                       // empty index: no candidates, as vq_index_search reports it
+        const int64_t count = (int64_t)nq * k;
+        hipLaunchKernelGGL(fill_no_result_kernel, dim3(cdiv(count, 256)), dim3(256), 0, x->stream, (int32_t*)d_ids, (float*)d_dist, count);
+        VQ_HIP(hipGetLastError());
+        return 0;
+    }
     return search_dispatch(x, (const float*)d_queries, nq, k, mode, (int32_t*)d_ids, (float*)d_dist);
 }
 

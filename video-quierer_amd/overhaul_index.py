@@ -23,7 +23,7 @@ from typing import Dict, List
 
 import numpy as np
 
-from video_quierer_amd.indexes.hnsw import MODE_AUTO, MODE_EXACT, HNSWIndex
+from video_quierer_amd.indexes.hnsw import MODE_AUTO, HNSWIndex
 
 logger = logging.getLogger(__name__)
 
@@ -35,7 +35,6 @@ class SimpleVideoIndex:
         self.video_hashes: Dict = {}
         self._dev = None          # HNSWIndex used as the raw device matrix
         self._pushed = 0
-        self._unit = True         # all rows unit-norm so far (the fp16 scan's error bound assumes it)
 
     def add_frame(self, embedding: np.ndarray, video_name: str, timestamp: float):
         self.embeddings.append(embedding.astype(np.float32))
@@ -60,7 +59,6 @@ class SimpleVideoIndex:
         self._dev._identity = False
         self._dev.element_count = n
         self._dev.entry_point = 0
-        self._unit = self._unit and bool(np.all(np.abs(np.einsum("ij,ij->i", block, block) - 1.0) < 1e-3))
         self._pushed = n
 
     def search(self, query_embedding: np.ndarray, k: int = 5) -> List[Dict]:
@@ -70,7 +68,9 @@ class SimpleVideoIndex:
         q = np.asarray(query_embedding)
         query_norm = (q / (np.linalg.norm(q) + 1e-10)).astype(np.float32)          # reference :50-51
         dev = self._dev
-        dev.search_mode = MODE_AUTO if self._unit else MODE_EXACT
+        # rows are stored as given: the library measures |row|^2 of what it holds and only takes its fp16 scan
+        # while the matrix is near-unit (include/vq_amd.h vq_index_add), so un-normalised embeddings stay exact
+        dev.search_mode = MODE_AUTO
         n, kk = len(self.embeddings), min(k, len(self.embeddings))
         unit = np.ascontiguousarray(query_norm[None, :])
         fetch = min(n, kk + 8)
@@ -110,7 +110,7 @@ class SimpleVideoIndex:
             self.video_hashes = data.get("video_hashes", {})
             if self._dev is not None:
                 self._dev.close()
-            self._dev, self._pushed, self._unit = None, 0, True
+            self._dev, self._pushed = None, 0
             logger.info(f"Loaded {len(self.embeddings)} embeddings from {cache_path}")
             return True
         except Exception as e:
