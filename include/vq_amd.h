@@ -80,7 +80,7 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
 #define VQ_ENC_F16_ATTN 0x400
 #define VQ_ENC_F16_FC1 0x800
 #define VQ_ENC_F16_FC2 0x1000
-#define VQ_ENC_MIXED (VQ_ENC_F16_FC1 | VQ_ENC_F16_FC2)
+#define VQ_ENC_MIXED (VQ_ENC_F16_QKV | VQ_ENC_F16_ATTN | VQ_ENC_F16_FC1 | VQ_ENC_F16_FC2)
 /* VQ_ENC_CONCURRENT: the caller keeps several encoder handles busy at once on separate HIP streams.  The
  * N = hidden GEMMs then keep 256-row tiles (150 dense workgroups at batch 256, leaving CUs to the other
  * streams: +7 % aggregate frames/s measured with 3 streams) instead of the 160-row tiles that spread one
@@ -212,6 +212,30 @@ int vq_index_set_stream(vq_index* idx, void* hip_stream);
 
 /* save / load support (hnsw.py:306-380): the stored (normalised) rows. */
 int vq_index_export(vq_index* idx, float* rows /*[size][dim]*/);
+
+/* ---- multi-GPU exchange over RCCL (xGMI): one process per GPU ------------------------------------
+ * The reference is single-device; these entry points are what a multi-GPU deployment of its
+ * ingest loop (src/video_search_system.py:152-181) and of its search (:297) adds: an all-gather of the per-shard
+ * embeddings before indexing, and for a row-sharded matrix an all-gather of the per-shard top-k followed by a
+ * k-way merge in the reference's (distance, id) order (src/indexes/hnsw.py:269).  librccl is loaded on first
+ * use.  Rank 0 makes the id (vq_comm_unique_id, 128 bytes) and ships it to the other ranks by any side
+ * channel (torch.distributed's store, a file, MPI); every rank then calls vq_comm_init after vq_init. */
+typedef struct vq_comm vq_comm;
+#define VQ_COMM_ID_BYTES 128
+int vq_comm_unique_id(void* out_id, int bytes);
+int vq_comm_init(int rank, int world, const void* unique_id, vq_comm** out);
+int vq_comm_destroy(vq_comm* comm);
+int vq_comm_info(vq_comm* comm, int* rank, int* world, int* rccl_version);
+/* counts[world]: rows each rank contributes (this rank's d_local holds counts[rank] x dim fp32); d_out receives
+ * sum(counts) x dim in rank (= frame) order on every rank.  Asynchronous on hip_stream. */
+int vq_allgather_rows(vq_comm* comm, const void* d_local, const int64_t* counts, int dim, void* d_out, void* hip_stream);
+/* This rank's index holds rows [row_offset, row_offset + size) of the global matrix.  Same modes and result
+ * layout as vq_index_search_device, ids are GLOBAL row numbers, identical on every rank.  world*k <= 1024. */
+int vq_index_search_sharded(vq_index* idx, vq_comm* comm, const void* d_queries_f32, int nq, int k, int mode,
+                            int64_t row_offset, void* d_ids_i32, void* d_dist_f32);
+/* The merge step alone: [world][nq][k] shard results with global ids (-1 / +inf = empty slot) -> [nq][k]. */
+int vq_merge_topk_device(const void* d_all_ids_i32, const void* d_all_dist_f32, int world, int nq, int k,
+                         void* d_ids_i32, void* d_dist_f32, void* hip_stream);
 
 /* Device timing of the scan kernels between begin/end (bench.py roofline leg). */
 #define VQ_IDX_NCLASS 6

@@ -78,3 +78,23 @@ def test_shard_range_partitions():
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
     # config 4: 4 videos x 1000 frames, video v on ranks {2v, 2v+1}, 500 frames each
     assert [shard_range(1000, r % 2, 2) for r in range(8)] == [(0, 500), (500, 1000)] * 4
+
+
+def test_bench_launches_its_own_ranks_when_typed_bare():
+    """`python bench.py --gpus N` with no launcher around it (how the driver types it): the parent starts N ranks
+    under torch.distributed.run before touching a GPU, relays rank 0's ONE JSON line and the ranks' exit code.
+    Rehearsed on CPU over gloo (--rehearse-cpu stands in for the encode; the exchange steps are the real ones)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse-cpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["rehearsal"] is True
+    assert out["config"]["gathered_rows"] == 2 * 256 and out["scaling"] == "weak" and out["value"] > 0
+    # a rank that dies takes the exit code with it and no result line is invented
+    p = subprocess.run(cmd, env=dict(env, VQ_BENCH_REHEARSE_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]

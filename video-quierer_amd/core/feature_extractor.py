@@ -14,8 +14,8 @@ What differs from the reference, deliberately:
 * Frames that are not 224x224 are resized on the GPU, bit-identically to Pillow (preprocess.py);
   ``resize_mode="clip_processor"`` selects the live path's short-edge-bicubic + centre-crop instead of the
   reference class's stretch.
-* GEMMs take 16-bit operands with fp32 accumulation: ``compute_dtype="mixed"`` (default: bf16 attention
-  GEMMs, fp16 MLP GEMMs), ``"bf16"``, ``"fp16"`` or ``"fp16:<group>+…"`` (encoder.py); every cosine score
+* GEMMs take 16-bit operands with fp32 accumulation: ``compute_dtype="mixed"`` (default: fp16, the
+  patch-embed GEMM in bf16), ``"bf16"``, ``"fp16"`` or ``"fp16:<group>+…"`` (encoder.py); every cosine score
   agrees with the fp32 reference within 1e-3 at the default (tests/test_gpu_parity.py).
 """
 from __future__ import annotations

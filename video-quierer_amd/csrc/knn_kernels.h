@@ -7,19 +7,6 @@
 
 namespace vq {
 
-// (distance, row) -> one 64-bit key whose unsigned order is the lexicographic
-// (distance asc, row asc) order of hnsw.py:269 `sorted(candidates)[:k]`.
-__host__ __device__ inline uint64_t dist_key(float d, uint32_t row) {
-    uint32_t u = __builtin_bit_cast(uint32_t, d);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone float -> uint
-    return ((uint64_t)u << 32) | row;
-}
-__host__ __device__ inline float key_dist(uint64_t k) {
-    uint32_t u = (uint32_t)(k >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __builtin_bit_cast(float, u);
-}
-
 // ---- row normalisation (HNSWIndex.add, hnsw.py:157) for device-resident rows ----
 // n2 = fp64 chain of x*x in index order; x <- fp32(x / fp32(sqrt(n2))).
 // One thread per row keeps the chain order; rows are staged through LDS in

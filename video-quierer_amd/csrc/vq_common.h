@@ -57,6 +57,20 @@ __host__ __device__ inline float bf16_to_f32(uint16_t h) {
     return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
 
+// ---- result ordering of the k-NN path (knn_kernels.h, knn_scan_f16.h, vq_comm.hip) ----
+// (distance, row) -> one 64-bit key whose unsigned order is the lexicographic
+// (distance asc, row asc) order of hnsw.py:269 `sorted(candidates)[:k]`.
+__host__ __device__ inline uint64_t dist_key(float d, uint32_t row) {
+    uint32_t u = __builtin_bit_cast(uint32_t, d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone float -> uint
+    return ((uint64_t)u << 32) | row;
+}
+__host__ __device__ inline float key_dist(uint64_t k) {
+    uint32_t u = (uint32_t)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -265,6 +265,24 @@ int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode
 
 }  // namespace
 
+// vq_comm.hip: this rank's part of a row-sharded search, on the index's stream (returned so that the exchange is
+// enqueued behind it).
+namespace vq {
+int index_search_local(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist,
+                       hipStream_t* stream_out, int64_t* size_out) {
+    std::lock_guard<std::mutex> lk(x->mu);
+    *stream_out = x->stream;
+    *size_out = x->size;
+    if (x->size == 0) {
+        const int64_t count = (int64_t)nq * k;
+        hipLaunchKernelGGL(fill_no_result_kernel, dim3(cdiv(count, 256)), dim3(256), 0, x->stream, d_ids, d_dist, count);
+        VQ_HIP(hipGetLastError());
+        return 0;
+    }
+    return search_dispatch(x, d_queries, nq, k, mode, d_ids, d_dist);
+}
+}  // namespace vq
+
 extern "C" {
 
 int vq_index_create(int dim, vq_index** out) {
