@@ -137,7 +137,7 @@ int vq_encoder_debug_read(vq_encoder* enc, const char* name, int rows, float* ou
 
 /* C[M][N] = A[M][K] * W[N][K]^T through the production MFMA mainloops (inputs
  * rounded from the given fp32, fp32 accumulate) — unit-test hook.
- * flags: bit 0 = fp16 inputs (else bf16); bits 1-2 = kernel (0 auto, 1 = 128x128
+ * flags: bit 0 = fp16 inputs (else bf16); bits 1-4 = kernel (0 auto, 1 = 128x128
  * two-phase, 2 = 256x256 phased). */
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C);
 
@@ -174,6 +174,9 @@ int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stam
  * 128x128, 2 = 256x256 four-phase, 3 = 256x256 ring; diag: bit0 no in-loop DMA, bit1 no ds_reads,
  * bit2 no MFMAs, bit3 no barriers (ring only). */
 int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, float* ms_avg);
+/* Diagnostic: average launch time of the deep-prefetch 256x256 mainloop on random data and the clock (GHz) the chip
+ * holds inside its K loop (d s_memtime / d s_memrealtime, median over workgroups). */
+int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz_median);
 
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;

@@ -93,12 +93,25 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
     const int rrow = lane >> 4, rcol = lane & 15;
     const int n = n_wave0 + rcol * 4;
     const f32x4 bias = epi.bias_at(n);
+    constexpr int FULL = MI / 2;          // passes over 32 rows; an odd MI adds a last pass over 16 rows
+    // Epilogues that read memory (residual RMW, position embedding) keep the NEXT pass's reads in flight while the
+    // current pass goes through LDS and out: one exposed round trip per tile instead of one per pass (the residual
+    // stream is 39 MB at batch 256, i.e. every read comes from beyond L2).
+    f32x4 loaded[2][8];
+    if constexpr (Epi::kLoads) {
 #pragma unroll
-    for (int pass = 0; pass < MI / 2; ++pass) {
-        f32x4 loaded[8];
+        for (int it = 0; it < (FULL > 0 ? 8 : 4); ++it) loaded[0][it] = epi.load(m_wave0 + it * 4 + rrow, n);
+    }
+#pragma unroll
+    for (int pass = 0; pass < FULL; ++pass) {
         if constexpr (Epi::kLoads) {
+            if (pass + 1 < FULL) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) loaded[it] = epi.load(m_wave0 + pass * 32 + it * 4 + rrow, n);
+                for (int it = 0; it < 8; ++it) loaded[(pass + 1) & 1][it] = epi.load(m_wave0 + (pass + 1) * 32 + it * 4 + rrow, n);
+            } else if (MI & 1) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) loaded[(pass + 1) & 1][it] = epi.load(m_wave0 + (MI - 1) * 16 + it * 4 + rrow, n);
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -110,16 +123,11 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + rrow;
             const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
-            epi.store(m_wave0 + pass * 32 + row, n, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
+            epi.store(m_wave0 + pass * 32 + row, n, v, bias, Epi::kLoads ? loaded[pass & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
     if constexpr (MI & 1) {               // odd block count: a last pass over 16 rows
         constexpr int base = (MI - 1) * 16;
-        f32x4 loaded[4];
-        if constexpr (Epi::kLoads) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) loaded[it] = epi.load(m_wave0 + base + it * 4 + rrow, n);
-        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
             *(f32x4*)(strip + frow * EPI_ROW_BYTES + (ni * 16 + fgrp * 4) * 4) = acc[MI - 1][ni];
@@ -127,7 +135,7 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
         for (int it = 0; it < 4; ++it) {
             const int row = it * 4 + rrow;
             const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
-            epi.store(m_wave0 + base + row, n, v, bias, Epi::kLoads ? loaded[it] : f32x4{0.f, 0.f, 0.f, 0.f});
+            epi.store(m_wave0 + base + row, n, v, bias, Epi::kLoads ? loaded[FULL & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
 }

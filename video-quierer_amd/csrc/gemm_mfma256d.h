@@ -1,0 +1,226 @@
+// 256x256x64 bf16/fp16 TN GEMM, third-generation mainloop: the four-phase schedule of gemm_mfma256.h with the
+// LDS-DMA prefetch running FIVE phases (1.25 K-tiles) ahead of the fragment reads instead of one to three.
+//
+// Same tile, wave layout (8 waves = 2 m x 4 n, 128 x 64 per wave), LDS image (2 K-tile buffers x 64 KiB, every
+// 8-row x 128-B piece lane-linear, 16-byte chunks XOR-swizzled by (row>>1)&7 on the DMA source and on the read) and
+// epilogue as gemm_tn256_kernel.  What changes is WHICH rows one staging unit covers and WHEN it is issued:
+//
+//   A wave reads, per K-tile, the sub-blocks of ITS OWN 128 x 64 tile: rows hm*64..+63 of its 128 A rows in phase 1
+//   (hm = 0) and phase 3 (hm = 1), columns hn*32..+31 of its 64 W rows in phase 1 (hn = 0) and phase 2 (hn = 1);
+//   the quadrant order is (0,0) (0,1) (1,1) (1,0) and both W sub-blocks stay in registers, so phase 4 reads nothing.
+//   A staging unit is therefore the set of LDS rows that ONE phase reads, over all eight waves (16 KiB, two 1-KiB
+//   pieces per wave): A0 = {wr*128 + 0..63}, A1 = {wr*128 + 64..127}, W0 = {wc*64 + 0..31}, W1 = {wc*64 + 32..63}.
+//   Unit deaths (last ds_read) per tile: A0 and W0 in phase 1, W1 in phase 2, A1 in phase 3 — the same order in
+//   which the next tile needs them — so each unit is refilled two or three phases after it died, for the tile
+//   after next (same buffer) or the next tile (other buffer):
+//
+//       phase 1 of tile t   reads A0(t) W0(t)   issues W1(t+1)      waits until W1(t) has landed
+//       phase 2             reads W1(t)         issues A1(t+1)      waits until A1(t) has landed
+//       phase 3             reads A1(t)         issues A0(t+2)      -
+//       phase 4             -                   issues W0(t+2)      waits until A0(t+1), W0(t+1) have landed
+//
+//   Every unit is issued 5-6 phases before its first read; about five units (80 KiB) are in flight per CU.  Each
+//   wait is a counted s_waitcnt vmcnt(8) in steady state (the four units issued after the awaited one stay in
+//   flight); the tail of the K loop uses the exact smaller counts.  Barriers are raw s_barrier; the two wave groups
+//   run staggered by one barrier as before.
+//
+// Hazards (b(k) = k-th barrier; phase P of group 0: read half before b(2P), MFMA half before b(2P+1); group 1 one
+// barrier later):
+//   RAW  a unit is awaited in the read half of phase P (every issuer, both groups: before b(2P) / b(2P+1)) and first
+//        read in the read half of phase P+1 (after b(2P+1) / b(2P+2)): every issuer's wait precedes a barrier the
+//        reader has passed.
+//   WAR  a unit is re-issued >= 2 phases after its last ds_read; those reads retire (lgkmcnt(0)) in the MFMA half of
+//        their phase, i.e. before b(2P+1) / b(2P+2), and the earliest re-issue (phase P+2, group 0) comes after b(2P+3).
+//
+// Requirements: M % 256 == 0, N % 256 == 0, K % 128 == 0 (two K-tiles per loop trip).
+#pragma once
+#include "vq_common.h"
+#include "gemm_mfma.h"
+#include "gemm_mfma256.h"
+
+namespace vq {
+
+template <bool IS_F16, class Epi, bool CLOCK = false>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
+                        const uint16_t* __restrict__ W, int ldw,
+                        int K, int tiles_n, Epi epi, int order2d,
+                        unsigned long long* __restrict__ clock_out = nullptr /* CLOCK builds: per-workgroup {d memtime, d memrealtime} around the K loop */) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int tm = wg / tiles_n, tn = wg % tiles_n;
+    if (order2d) tile_coords(wg, (int)gridDim.x / tiles_n, tiles_n, tm, tn);
+    const int m0 = tm * G2_BM;
+    const int n0 = tn * G2_BN;
+
+    // ---- LDS-DMA: wave w fills pieces p = 2w, 2w+1 (8 rows x 128 B each) of every staging unit ----
+    // A unit hm: piece p -> rows (p>>3)*128 + hm*64 + (p&7)*8 ..+7        (LDS: A region, row*128 B)
+    // W unit hn: piece p -> rows (p>>2)*64  + hn*32 + (p&3)*8 ..+7        (LDS: W region, row*128 B)
+    const int srow = lane >> 3, sslot = lane & 7;
+    const uint16_t* a_src[2][2];
+    const uint16_t* w_src[2][2];
+    int a_dst[2][2], w_dst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave * 2 + i;
+            const int arow0 = (p >> 3) * 128 + h * 64 + (p & 7) * 8;
+            const int wrow0 = (p >> 2) * 64 + h * 32 + (p & 3) * 8;
+            const int ar = arow0 + srow, wrw = wrow0 + srow;
+            a_src[h][i] = A + (size_t)(m0 + ar) * lda + (sslot ^ ((ar >> 1) & 7)) * 8;
+            w_src[h][i] = W + (size_t)(n0 + wrw) * ldw + (sslot ^ ((wrw >> 1) & 7)) * 8;
+            a_dst[h][i] = arow0 * 128;                       // A region = first 32 KiB of a buffer (two 16-KiB halves)
+            w_dst[h][i] = 2 * G2_HALF + wrow0 * 128;         // W region = second 32 KiB
+        }
+
+    auto stage_a = [&](int buf, int hm, int kt) {
+        char* base = smem + buf * G2_BUF;
+        const int koff = kt * G2_BK;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
+    };
+    auto stage_w = [&](int buf, int hn, int kt) {
+        char* base = smem + buf * G2_BUF;
+        const int koff = kt * G2_BK;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets (identical to gemm_tn256_kernel) ----
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;                                          // + mi*2048
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;   // + ni*2048
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag af[4][2], wf[2][2][2];          // one A sub-block (64 rows); BOTH W sub-blocks (2 x 32 cols)
+
+    const int nk = K / G2_BK;
+
+    auto load_a = [&](const char* buf, int hm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf, int hn) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[hn][j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
+    };
+    auto mfma_quadrant = [&](int hm, int hn) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    auto tile = [&](int kt, int bufi) {
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+        // phase 1: quadrant (0,0)
+        load_a(buf, 0); load_w(buf, 0);
+        if (next) { stage_w(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }       // newer than W1(t): A1(t) A0(t+1) W0(t+1) W1(t+1)
+        else      { VQ_VMCNT(2); }                                     //                   A1(t)
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 0);
+        barrier();
+        // phase 2: quadrant (0,1)
+        load_w(buf, 1);
+        if (next) { stage_a(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }       // newer than A1(t): A0(t+1) W0(t+1) W1(t+1) A1(t+1)
+        else      { VQ_VMCNT(0); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 1);
+        barrier();
+        // phase 3: quadrant (1,1)
+        load_a(buf, 1);
+        if (next2) stage_a(bufi, 0, kt + 2);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 1);
+        barrier();
+        // phase 4: quadrant (1,0): no fragment reads (A1 and W0 are in registers)
+        if (next2)     { stage_w(bufi, 0, kt + 2); VQ_VMCNT(8); }      // newer than W0(t+1): W1(t+1) A1(t+1) A0(t+2) W0(t+2)
+        else if (next) { VQ_VMCNT(4); }                                //                     W1(t+1) A1(t+1)
+        barrier();
+        mfma_quadrant(1, 0);
+        barrier();
+    };
+
+    // ---- prologue: tile 0 complete + A0, W0 of tile 1 in flight; A0(0), W0(0) landed ----
+    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
+    if (nk > 1) { stage_a(1, 0, 1); stage_w(1, 0, 1); VQ_VMCNT(8); }
+    else        { VQ_VMCNT(4); }
+    barrier();
+
+    unsigned long long c0 = 0, r0 = 0;
+    if constexpr (CLOCK) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile(kt, 0);
+        tile(kt + 1, 1);
+    }
+    if (wr == 0) barrier();               // every wave executes the same number of barriers
+    barrier();                            // both groups past their last fragment reads before LDS is reused
+#undef VQ_VMCNT
+
+    if constexpr (CLOCK) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) { clock_out[blockIdx.x * 2] = c1 - c0; clock_out[blockIdx.x * 2 + 1] = r1 - r0; }
+    }
+
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                              int M, int N, int K, const Epi& epi) {
+    VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
+             "gemm_tn256d: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn256d: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    static bool attr_set = false;       // per instantiation; one device per process (vq_init)
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<IS_F16, Epi>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
+    hipLaunchKernelGGL((gemm_tn256d_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
+                       A, lda, W, ldw, K, tiles_n, epi, gemm_order2d(), (unsigned long long*)nullptr);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vq

@@ -19,10 +19,12 @@
 //     tiles_n >= 8 (else (32/tiles_n) x tiles_n), so operand panels are shared in that XCD's L2.
 #pragma once
 #include "vq_common.h"
+#include <cstring>
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
 #include "gemm_mfma160.h"
 #include "gemm_mfma256w4.h"
+#include "gemm_mfma256d.h"
 
 namespace vq {
 
@@ -269,9 +271,21 @@ static int launch_gemm_tn256p(hipStream_t st, const uint16_t* A, int lda, const 
 }
 
 // Dispatch: the phased 256x256 kernel when the problem tiles by it and yields enough
-// workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 3 = ring,
+// workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 8 = four-phase with the deep prefetch (gemm_mfma256d.h, the default 256x256 mainloop), 3 = ring,
 // 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles, 7 = four-wave 256x256.  Auto picks the 160-row tiles when they put one workgroup on
 // more CUs than 256-row tiles would (VQ_AMD_GEMM160=0 disables that).
+static inline bool gemm_use_deep() {          // $VQ_AMD_GEMM256=4phase keeps the second-generation mainloop (A/B switch)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM256"); v = (e && !strcmp(e, "4phase")) ? 0 : 1; }
+    return v != 0;
+}
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256_best(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                                  int M, int N, int K, const Epi& epi) {
+    return gemm_use_deep() ? launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi)
+                           : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+}
+
 static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one launch per GEMM
     static int v = -1;
     if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_TAIL"); v = (e && atoi(e) == 0) ? 0 : 1; }
@@ -292,6 +306,8 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
         return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
 #endif
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
+    if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 2) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
 #ifdef VQ_GEMM_EXPERIMENTS
     if (fits256 && want256 && force == 4) return launch_gemm_tn256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
@@ -309,12 +325,12 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
             const int main_rows_tiles = (int)((tiles - rem) / tiles_n);          // whole tile rows inside the full rounds
             const int m_main = main_rows_tiles * G2_BM;
             if (m_main > 0 && m_main < M) {
-                VQ_TRY((launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, m_main, N, K, epi)));
+                VQ_TRY((launch_gemm_tn256_best<IS_F16>(st, A, lda, W, ldw, m_main, N, K, epi)));
                 return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
             }
         }
     }
-    if (fits256 && want256 && force != 1) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (fits256 && want256 && force != 1) return launch_gemm_tn256_best<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
 

@@ -6,6 +6,7 @@
 #include "gemm_mfma256.h"
 #include "gemm_mfma256p.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -87,7 +88,7 @@ int vq_init(int device_ordinal) {
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C) {
     VQ_TRY(require_init());
     VQ_CHECK(A && W && C, "vq_debug_gemm: null argument");
-    const int use_f16 = flags & 1, force = (flags >> 1) & 7;    // force: 0 auto, 1 = 128x128, 2 = four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring, 7 = four-wave 256x256
+    const int use_f16 = flags & 1, force = (flags >> 1) & 15;    // force: 0 auto, 1 = 128x128, 2 = four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring, 7 = four-wave 256x256
     std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
     for (size_t i = 0; i < a16.size(); ++i)
         a16[i] = use_f16 ? __builtin_bit_cast(uint16_t, (_Float16)A[i]) : f32_to_bf16_rne(A[i]);
@@ -160,6 +161,7 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
         if (kernel == 3 || kernel == 4 || kernel == 7)
             return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", kernel);
 #endif
+        if (kernel == 8) return launch_gemm_tn256d<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         return launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, nullptr, diag);
@@ -175,6 +177,48 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
     return rc;
+}
+
+// Diagnostic: the clock the chip holds inside the deep-prefetch mainloop (MI355X_MICROARCH.md "DVFS give-back" item 6):
+// d s_memtime / d s_memrealtime x 100 MHz around the K loop, median over workgroups, after `reps` back-to-back launches.
+int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz_median) {
+    VQ_TRY(require_init());
+    VQ_CHECK(ms_avg && ghz_median && reps > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0, "vq_debug_gemm_clock: bad argument");
+    uint16_t *dA = nullptr, *dW = nullptr; float* dC = nullptr; unsigned long long* dS = nullptr;
+    const int wgs = (M / 256) * (N / 256);
+    VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2)); VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4));
+    VQ_HIP(hipMalloc(&dS, (size_t)wgs * 16));
+    std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t r = 4242;
+    for (auto& v : a16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    for (auto& v : w16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    typedef EpiStoreF32 E;
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    hipEvent_t e0, e1;
+    VQ_HIP(hipEventCreate(&e0)); VQ_HIP(hipEventCreate(&e1));
+    auto once = [&]() {
+        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, true>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr,
+                           dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
+    };
+    for (int i = 0; i < 3; ++i) once();
+    VQ_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) once();
+    VQ_HIP(hipEventRecord(e1, nullptr));
+    VQ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / reps;
+    std::vector<unsigned long long> st((size_t)wgs * 2);
+    VQ_HIP(hipMemcpy(st.data(), dS, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<float> ghz;
+    for (int i = 0; i < wgs; ++i) if (st[2 * i + 1]) ghz.push_back((float)st[2 * i] / (float)st[2 * i + 1] * 0.1f);
+    std::sort(ghz.begin(), ghz.end());
+    *ghz_median = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dS);
+    return 0;
 }
 
 }  // extern "C"
