@@ -206,8 +206,9 @@ def main():
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     conc = nstreams > 1 if os.environ.get("VQ_BENCH_CONCURRENT") is None else os.environ["VQ_BENCH_CONCURRENT"] == "1"
-    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=conc)
-            for _ in range(nstreams)]
+    # the handles share ONE device copy of the weights (vq_encoder_create_shared): each in-flight batch only adds a workspace
+    encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=conc)]
+    encs += [encs[0].clone(concurrent=conc) for _ in range(nstreams - 1)]
     for e_, s_ in zip(encs, streams):
         e_.set_stream(s_.cuda_stream)
     enc, stream = encs[0], streams[0]
@@ -290,6 +291,7 @@ def main():
                                 f"configs[4] model: batch-{BATCH} ViT-L/14@336 encode of synthetic 336x336 RGB uint8 frames, ")
                                + "device-resident input (H2D excluded), seeded random-init weights",
                    "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,
+                   "weight_copies_per_gpu": 1,
                    "timed_frames": world * args.steps * BATCH,
                    "parallelism": f"dp{world} (frame shards; all-gather of embeddings per step)" if world > 1 else "single GPU"},
         "world": {"size": world, "backend": ("nccl = RCCL %s" % ".".join(map(str, torch.cuda.nccl.version()))) if world > 1 and backend == "nccl" else backend if world > 1 else None,

@@ -88,6 +88,10 @@ int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int
 #define VQ_ENC_CONCURRENT 2
 int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, int n_weights,
                          int max_batch, int flags, vq_encoder** out);
+/* Another handle on the SAME device weights (own stream, workspace and profiling state): for callers that keep
+ * several batches in flight.  flags: VQ_ENC_CONCURRENT only (operand types are the parent's).  The weights live
+ * until the last handle using them is destroyed, in any order. */
+int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_encoder** out);
 int vq_encoder_destroy(vq_encoder* enc);
 
 /* extract_batch (feature_extractor.py:137-177) for uint8 frames already at

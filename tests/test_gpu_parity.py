@@ -17,7 +17,7 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-GEMM_KERNELS = [1, 2, 5, 8]  # 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave: `make EXPERIMENTS=1` builds only)
+GEMM_KERNELS = [1, 2, 5, 8, 9]  # 9 = two-phase deep; 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave: `make EXPERIMENTS=1` builds only)
 
 
 @pytest.mark.parametrize("kernel", GEMM_KERNELS)
@@ -131,6 +131,28 @@ def test_encoder_fp16_operands_are_8x_closer(gpu_lib, b32_weights, golden_encode
     diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
     assert diff.max() <= 3e-4
     print(f"fp16 operands: max L2 err {err.max():.2e}, max score diff {diff.max():.2e}")
+
+
+def test_shared_weight_handles(gpu_lib, b32_weights):
+    """vq_encoder_create_shared: clones run on the parent's device weights with their own stream and workspace; results
+    are bit-identical to the parent's (same kernels), concurrent use is safe, and either side may be closed first."""
+    from concurrent.futures import ThreadPoolExecutor
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    parent = VitEncoder(VIT_B_32, b32_weights, max_batch=16, concurrent=True)
+    a, b = parent.clone(), parent.clone(max_batch=8)
+    frames = synth_frames(16, seed=21)
+    want = parent.encode(frames)
+    with ThreadPoolExecutor(3) as pool:
+        got = list(pool.map(lambda h: h.encode(frames), (parent, a, b)))       # b runs two passes of 8
+    assert all(np.array_equal(g, want) for g in got[:2])
+    assert np.abs(got[2] - want).max() <= 2e-3                                  # batch 8: other GEMM row padding
+    parent.close()                                                              # the clones keep the weights alive
+    assert np.array_equal(a.encode(frames), want)
+    c = a.clone()
+    a.close()
+    assert np.array_equal(c.encode(frames), want)
+    b.close(); c.close()
 
 
 def test_encoder_batch_shapes_and_paths(encoder, b32_weights):
@@ -363,6 +385,52 @@ def test_config1_recall_by_operand_type(gpu_lib, b32_weights, golden_knn, golden
     idx.close()
 
 
+# ------------------------------------------------------------------ end to end (config 4 on one GPU)
+def test_config4_end_to_end_on_one_gpu(gpu_lib):
+    """configs[3]: 4 videos x 1000 synthetic frames (host uint8 frame dicts, as frame_extractor.py yields them) ->
+    FeatureExtractor.extract_from_video_frames -> OptimizedHNSWIndex.add_batch with the caller's string ids
+    f"{video_id}_{i}" (video_search_system.py:164-181) -> 1000 queries, k = 10, against the exact oracle on the stored
+    rows in the reference's (distance, id) order — ids are strings, so ties sort lexicographically, not by row.
+    (The 8-GPU form shards the same frame ranges over ranks and all-gathers the rows: tests/test_distributed_cpu.py,
+    test_native_comm_world_of_one_over_rccl.)"""
+    from video_quierer_amd.core.feature_extractor import FeatureExtractor
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    videos, per, nq, k = 4, 1000, 1000, 10
+    rng = np.random.default_rng(1000)
+    frames = rng.integers(0, 255, (videos * per, 224, 224, 3), dtype=np.uint8)
+    frames[10] = frames[9]                     # "video0_10" sorts before "video0_9": a tie the row order would get wrong
+    fds = [{"frame": frames[g], "timestamp": (g % per) / 30.0, "frame_number": g % per, "video_id": f"video{g // per}"}
+           for g in range(videos * per)]
+    fx = FeatureExtractor(model_name="seed:1234", batch_size=32, device_batch=256)
+    out = fx.extract_from_video_frames(fds)
+    assert [o["frame_number"] for o in out] == [g % per for g in range(videos * per)] and "features" in out[0]
+    emb = np.stack([o["features"] for o in out])
+    assert emb.shape == (4000, 512) and np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    assert np.array_equal(emb[9], emb[10])
+    ids = [f"{fd['video_id']}_{fd['frame_number']}" for fd in fds]
+    idx = OptimizedHNSWIndex(dimension=512)
+    idx.add_batch(list(emb), ids)
+    assert idx.size() == 4000
+    qrng = np.random.default_rng(5)
+    src = qrng.integers(0, len(emb), nq)
+    src[0] = 9
+    queries = emb[src] + 0.05 * qrng.standard_normal((nq, 512)).astype(np.float32)
+    queries[0] = emb[9]
+    res = idx.search_batch(list(queries), k)
+    stored = idx._export()
+    uq = np.stack([q / np.linalg.norm(q) for q in queries]).astype(np.float32)
+    rows, dist = knn_oracle.topk(stored, uq, k + 8)                      # a few extra so that a tie group at rank k is whole
+    for i in range(nq):
+        want = sorted((d, ids[r]) for r, d in zip(rows[i], dist[i]))[:k]
+        assert [r["id"] for r in res[i]] == [w[1] for w in want], i
+        assert np.array_equal(np.array([r["distance"] for r in res[i]], dtype=np.float32), np.array([w[0] for w in want], dtype=np.float32))
+    assert [r["id"] for r in res[0][:2]] == ["video0_10", "video0_9"] and res[0][0]["distance"] == res[0][1]["distance"]
+    single = idx.search(queries[5], k)                                   # the one-query call the reference makes (:297)
+    assert [r["id"] for r in single] == [r["id"] for r in res[5]]
+    idx.close()
+    fx.thread_pool.shutdown()
+
+
 # ------------------------------------------------------------------ fp16 MFMA scan + exact re-score
 def _scan_vs_oracle(vecs, qs, k, expect_fallback=None):
     from video_quierer_amd.indexes.hnsw import MODE_FP16, OptimizedHNSWIndex
@@ -392,6 +460,24 @@ def test_fp16_scan_random_matches_oracle_bit_exact(gpu_lib):
     assert st["exact_fallback"] <= 2                                   # random data: the proof closes almost always
     _scan_vs_oracle(vecs[:16500], qs[:17], 1)
     _scan_vs_oracle(vecs[:16500], qs[:17], 32)
+
+
+def test_small_batch_streaming_scan_matches_oracle_bit_exact(gpu_lib):
+    """Batches of <= 64 queries (the reference searches one query at a time, video_search_system.py:297) take the
+    HBM-bound streaming scan (scan3_f16_top2_kernel, 16 queries per pass): same proof, same bit-exact answers."""
+    rng = np.random.default_rng(41)
+    vecs = rng.standard_normal((20001, 512)).astype(np.float32)       # ragged last stream (33 rows)
+    qs = rng.standard_normal((64, 512)).astype(np.float32)
+    for nq, k in ((1, 10), (1, 1), (5, 20), (16, 10), (17, 10), (64, 32)):
+        st = _scan_vs_oracle(vecs, qs[:nq], k)
+        assert st["exact_fallback"] <= 1, (nq, k, st)
+    _scan_vs_oracle(vecs[:16400, :256], qs[:3, :256], 5)                # dim 256 instantiation
+    _scan_vs_oracle(vecs[:16400, :128], qs[:3, :128], 5)                # other dims keep the MFMA-tile scan
+    # near-duplicate runs: stream rescans and the exact fallback behind the streaming scan
+    centers = rng.standard_normal((200, 512)).astype(np.float32)
+    dup = (np.repeat(centers, 100, axis=0) + 1e-3 * rng.standard_normal((20000, 512))).astype(np.float32)
+    st = _scan_vs_oracle(dup, centers[:9] + 0, 10)
+    print("streaming scan, clustered data:", st)
 
 
 def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):

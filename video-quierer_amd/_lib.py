@@ -44,6 +44,7 @@ SIGNATURES = {
     "vq_version": (c_char_p, []),
     "vq_encoder_create": (c_int, [POINTER(VitConfigC), POINTER(POINTER(c_float)), c_int, c_int, POINTER(c_void_p)]),
     "vq_encoder_create_ex": (c_int, [POINTER(VitConfigC), POINTER(POINTER(c_float)), c_int, c_int, c_int, POINTER(c_void_p)]),
+    "vq_encoder_create_shared": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "vq_encoder_destroy": (c_int, [c_void_p]),
     "vq_encoder_encode_u8": (c_int, [c_void_p, POINTER(c_uint8), c_int, c_int, POINTER(c_float)]),
     "vq_encoder_encode_u8_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -103,9 +103,9 @@ class FeatureExtractor:
             self.config = cfg
             self.model = VitEncoder(cfg, weights, max_batch=self.device_batch, device=self._ordinal,
                                     compute_dtype=self.compute_dtype)
-            # handles a long extract_from_video_frames alternates between (created now: the weights are at hand)
-            self._ingest = [VitEncoder(cfg, weights, max_batch=self.device_batch, device=self._ordinal,
-                                       compute_dtype=self.compute_dtype, concurrent=True)
+            # handles a long extract_from_video_frames alternates between: own streams and workspaces on the one
+            # device copy of the weights (vq_encoder_create_shared)
+            self._ingest = [self.model.clone(concurrent=True)
                             for _ in range(self.ingest_streams if self.ingest_streams > 1 else 0)]
             for m in self._ingest or [self.model]:
                 m.prewarm_staged()

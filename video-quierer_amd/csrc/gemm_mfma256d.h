@@ -203,6 +203,169 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two-phase variant: the same staging units and LDS image, but a K-tile is TWO phases of 32 MFMAs instead of four
+// of 16 — half the barriers (4 per K-tile) and half the points where the first MFMA waits for its fragments:
+//
+//     phase A of tile t   reads A0 W0 W1 (16 ds_read_b128)   issues A0 W0 W1 of tile t+1   waits until A1(t) has landed
+//                         32 MFMAs: quadrants (0,0) (0,1)
+//     phase B             reads A1 (8 ds_read_b128)          issues A1 of tile t+1         waits until A0 W0 W1 (t+1) have landed
+//                         32 MFMAs: quadrants (1,1) (1,0)
+//
+// Every unit is re-issued two phases after its last read (WAR) and awaited one phase before its first read (RAW),
+// exactly as in the four-phase schedule above; the waits are vmcnt(6) / vmcnt(2) in steady state.
+template <bool IS_F16, class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
+                        const uint16_t* __restrict__ W, int ldw,
+                        int K, int tiles_n, Epi epi, int order2d) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int tm = wg / tiles_n, tn = wg % tiles_n;
+    if (order2d) tile_coords(wg, (int)gridDim.x / tiles_n, tiles_n, tm, tn);
+    const int m0 = tm * G2_BM;
+    const int n0 = tn * G2_BN;
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    const uint16_t* a_src[2][2];
+    const uint16_t* w_src[2][2];
+    int a_dst[2][2], w_dst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave * 2 + i;
+            const int arow0 = (p >> 3) * 128 + h * 64 + (p & 7) * 8;
+            const int wrow0 = (p >> 2) * 64 + h * 32 + (p & 3) * 8;
+            const int ar = arow0 + srow, wrw = wrow0 + srow;
+            a_src[h][i] = A + (size_t)(m0 + ar) * lda + (sslot ^ ((ar >> 1) & 7)) * 8;
+            w_src[h][i] = W + (size_t)(n0 + wrw) * ldw + (sslot ^ ((wrw >> 1) & 7)) * 8;
+            a_dst[h][i] = arow0 * 128;
+            w_dst[h][i] = 2 * G2_HALF + wrow0 * 128;
+        }
+    auto stage_a = [&](int buf, int hm, int kt) {
+        char* base = smem + buf * G2_BUF;
+        const int koff = kt * G2_BK;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
+    };
+    auto stage_w = [&](int buf, int hn, int kt) {
+        char* base = smem + buf * G2_BUF;
+        const int koff = kt * G2_BK;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag af[4][2], wf[4][2];             // one A sub-block (64 rows); the wave's whole W block (64 cols)
+
+    const int nk = K / G2_BK;
+    auto load_a = [&](const char* buf, int hm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[j][ks] = *(const frag*)(buf + w_base + j * 2048 + slot[ks]);
+    };
+    auto mfma_half = [&](int hm) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[hm * 4 + i][j] = op::run(wf[j][ks], af[i][ks], acc[hm * 4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    auto tile = [&](int kt, int bufi) {
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < nk;
+        // phase A: rows 0..63 of the wave's tile x all 64 columns
+        load_a(buf, 0); load_w(buf);
+        if (next) { stage_a(bufi ^ 1, 0, kt + 1); stage_w(bufi ^ 1, 0, kt + 1); stage_w(bufi ^ 1, 1, kt + 1); VQ_VMCNT(6); }
+        else      { VQ_VMCNT(0); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_half(0);
+        barrier();
+        // phase B: rows 64..127
+        load_a(buf, 1);
+        if (next) { stage_a(bufi ^ 1, 1, kt + 1); VQ_VMCNT(2); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_half(1);
+        barrier();
+    };
+
+    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
+    VQ_VMCNT(2);
+    barrier();
+
+    if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile(kt, 0);
+        tile(kt + 1, 1);
+    }
+    if (wr == 0) barrier();
+    barrier();
+#undef VQ_VMCNT
+
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                              int M, int N, int K, const Epi& epi) {
+    VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
+             "gemm_tn256e: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn256e: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256e_kernel<IS_F16, Epi>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
+    hipLaunchKernelGGL((gemm_tn256e_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
+                       A, lda, W, ldw, K, tiles_n, epi, gemm_order2d());
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                               int M, int N, int K, const Epi& epi) {

@@ -31,6 +31,7 @@
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
 #include "knn_kernels.h"
+#include "knn_scan_small.h"
 
 namespace vq {
 
@@ -423,7 +424,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                            const float* __restrict__ rows, int64_t n_valid, int dim,
                            const float* __restrict__ queries, int nq, int k,
                            int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
-                           int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2 streams*/,
+                           int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2, 3: scan3_f16_top2 streams*/,
                            float eps_rows /* scan_eps_unit(dim) x the largest |row| in the index */) {
     __shared__ float kept_v[RV_QPW][RV_SHARES * RV_KEEP];      // kept key values (with packed index bits)
     __shared__ int kept_s[RV_QPW][RV_SHARES * RV_KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
@@ -517,7 +518,8 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         int row = -1; float d = __builtin_inff();
         if (src >= 0 && q_live && cand_key[ql][c] > NEG) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[ql][c]);
-            const int64_t r = layout == 2 ? scan2_row_of(src >> 1, (int)(kb & 127u)) : scan_row_of(src >> 1, (int)(kb & 127u));
+            const int64_t r = layout == 3 ? scan3_row_of(src >> 1, (int)(kb & 127u))
+                            : layout == 2 ? scan2_row_of(src >> 1, (int)(kb & 127u)) : scan_row_of(src >> 1, (int)(kb & 127u));
             if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
         }
         cand_row[ql][c] = row; cand_dist[ql][c] = d;
@@ -577,7 +579,8 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         const float* qv2 = queries + (size_t)(q0 + qq) * dim;
         for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
             const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
-            const int64_t r = layout == 2 ? scan2_row_of(resc_stream[qq][which], local) : scan_row_of(resc_stream[qq][which], local);
+            const int64_t r = layout == 3 ? scan3_row_of(resc_stream[qq][which], local)
+                            : layout == 2 ? scan2_row_of(resc_stream[qq][which], local) : scan_row_of(resc_stream[qq][which], local);
             int row = -1; float d = __builtin_inff();
             if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv2, dim); }
             cand_row[qq][RV_C + i] = row; cand_dist[qq][RV_C + i] = d;

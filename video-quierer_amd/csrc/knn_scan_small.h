@@ -1,0 +1,85 @@
+// Small-batch scan: the reference's own call pattern is ONE query at a time, k*2 results
+// (src/video_search_system.py:297 `index.search(query_vector, k * 2)`), i.e. a matrix-vector product: every
+// fp16 row is read once from HBM per pass and does 2*Q FLOP per element — HBM-bound for Q below ~300
+// (SURVEY.md §8d).  The 256-query MFMA tile of scan2_f16_top2_kernel wastes 255/256 of its matrix work there.
+//
+// This kernel streams the fp16 matrix straight into MFMA operand registers, no LDS:
+//   one wave = one stream of 128 consecutive rows = 8 blocks of 16 rows; per block 16 wave-wide 16-byte loads
+//   (lane l: row l&15, halves 32*ks + 8*(l>>4) ..+7 — exactly the A fragment of v_mfma_f32_16x16x32_f16), the
+//   next block's 16 KiB in flight while the current one is multiplied; up to 16 queries are the B operand and
+//   live in registers for the whole kernel (dim/32 fragments).  D[row][query]: lane (q = l&15, g = l>>4) gets
+//   rows 4g..4g+3 of the block; it folds its 32 scores per stream into a top-2 (score with the 7-bit local row
+//   index in the low mantissa bits, as scan*_f16_top2 do), the four lanes of a query merge their top-2 by
+//   shuffles, and lane g = 0 writes the stream's two keys.  Key layout 3 for rescore_verify_kernel:
+//   row = stream*128 + local.  More than 16 queries: one pass per 16 (blockIdx.y), Q <= 64.
+#pragma once
+#include "vq_common.h"
+#include "gemm_mfma.h"
+
+namespace vq {
+
+constexpr int SCAN3_QB = 16;            // queries per pass
+constexpr int SCAN3_MAX_Q = 64;         // beyond this the 256-query MFMA tile wins
+
+__host__ __device__ inline int64_t scan3_row_of(int64_t stream, int local) { return stream * 128 + local; }
+
+template <int NKS>                      // dim / 32
+__global__ __launch_bounds__(256, 2)
+void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, const uint16_t* __restrict__ X16,
+                           int64_t n_valid, int64_t streams, int64_t q_pad, uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+    typedef mfma_op<true> op;
+    typedef op::frag frag;
+    constexpr int DIM = NKS * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t stream = (int64_t)blockIdx.x * 4 + wave;
+    if (stream >= streams) return;                         // wave-uniform; no barriers below
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.y * SCAN3_QB;
+
+    frag qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        qf[ks] = *(const frag*)(Q16 + (size_t)(q0 + r16) * DIM + ks * 32 + g * 8);
+
+    const uint16_t* xrow = X16 + ((size_t)stream * 128 + r16) * DIM + g * 8;
+    frag xf[2][NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) xf[0][ks] = *(const frag*)(xrow + ks * 32);
+
+    const float NEG = -__builtin_inff(), MASKED = -3.0e38f;   // finite sentinel: see scan_f16_top2_kernel
+    float m1 = NEG, m2 = NEG;
+    const bool ragged = (stream + 1) * 128 > n_valid;      // wave-uniform
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+        if (rb + 1 < 8) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) xf[(rb + 1) & 1][ks] = *(const frag*)(xrow + (size_t)(rb + 1) * 16 * DIM + ks * 32);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) acc = op::run(xf[rb & 1][ks], qf[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r];
+            const int local = rb * 16 + 4 * g + r;
+            if (ragged && stream * 128 + local >= n_valid) v = MASKED;
+            const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)local);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, kf);
+            m1 = fmaxf(m1, kf);
+        }
+    }
+    // merge the four row groups of a query (lanes l, l^16, l^32, l^48): top-2 of two sorted pairs
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float b1 = __shfl_xor(m1, o), b2 = __shfl_xor(m2, o);
+        const float lo = fminf(m1, b1);
+        m1 = fmaxf(m1, b1);
+        m2 = fmaxf(lo, fmaxf(m2, b2));
+    }
+    if (g == 0)
+        *(uint2*)(keys + ((size_t)stream * q_pad + q0 + r16) * 2) =
+            uint2{__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m2)};
+}
+
+}  // namespace vq

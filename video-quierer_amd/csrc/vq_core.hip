@@ -162,6 +162,7 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
             return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", kernel);
 #endif
         if (kernel == 8) return launch_gemm_tn256d<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        if (kernel == 9) return launch_gemm_tn256e<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         return launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, nullptr, diag);

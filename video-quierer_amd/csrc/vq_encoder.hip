@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 #include <thread>
@@ -53,6 +54,8 @@ struct vq_encoder {
     hipStream_t own_stream = nullptr;   // created by the handle
     std::mutex mu;
     Arena arena;
+    std::shared_ptr<void> arena_owner;     // frees arena.base when the last handle using it goes
+    std::shared_ptr<void> weights_owner;   // vq_encoder_create_shared: the parent's arena, where this handle's weights live
     // weights
     uint16_t* w_patch = nullptr; float *b_patch = nullptr, *cls = nullptr, *pos = nullptr;
     float *pre_g = nullptr, *pre_b = nullptr, *post_g = nullptr, *post_b = nullptr, *w_proj = nullptr;
@@ -410,6 +413,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
     if (he != hipSuccess) { delete e; return fail(VQ_ERR_OOM, "vq_encoder_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
     e->arena.size = bytes;
+    e->arena_owner = std::shared_ptr<void>(e->arena.base, [](void* p) { (void)hipFree(p); });
     he = hipMemset(e->arena.base, 0, bytes);
     if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
     he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -498,6 +502,58 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     return 0;
 }
 
+// A second handle on the SAME weights: own stream, own workspace, own profiling state.  What a caller that keeps
+// several batches in flight needs (bench.py --streams, the ingest loop's alternating handles) without copying the
+// 176 MB of weights per handle.  The weights stay alive until the last handle that uses them is destroyed.
+int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_encoder** out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(parent && out && !parent->is_text, "vq_encoder_create_shared: needs an image-encoder handle");
+    VQ_CHECK(max_batch > 0 && max_batch <= 8192, "vq_encoder_create_shared: max_batch %d out of range", max_batch);
+    const vq_vit_config c = parent->cfg;
+    vq_encoder* e = new vq_encoder();
+    e->cfg = c; e->tokens = parent->tokens; e->patches = parent->patches; e->grid = parent->grid; e->patch_k = parent->patch_k;
+    e->max_batch = max_batch;
+    e->f16_mask = parent->f16_mask;                          // the weights are already stored in these types
+    e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
+    if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    e->attn_simple = parent->attn_simple; e->prune_last = parent->prune_last;
+    e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
+    e->prow_pad = round_up((int64_t)max_batch * e->patches, 256);
+    e->weights_owner = parent->weights_owner ? parent->weights_owner : parent->arena_owner;   // a clone of a clone still pins the original weights
+    e->w_patch = parent->w_patch; e->b_patch = parent->b_patch; e->cls = parent->cls; e->pos = parent->pos;
+    e->pre_g = parent->pre_g; e->pre_b = parent->pre_b; e->post_g = parent->post_g; e->post_b = parent->post_b;
+    e->w_proj = parent->w_proj; e->layers = parent->layers;
+    auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
+    const size_t H = c.hidden, M = c.mlp;
+    size_t bytes = 0;
+    auto add = [&](size_t b) { bytes = ((bytes + 255) & ~(size_t)255) + b; };
+    add((size_t)max_batch * c.image_size * c.image_size * 3);
+    add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * c.proj_dim * 4);
+    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
+    add(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k) * 2);
+    bytes += 4096;
+    hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
+    if (he != hipSuccess) { delete e; return fail(VQ_ERR_OOM, "vq_encoder_create_shared: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
+    e->arena.size = bytes;
+    e->arena_owner = std::shared_ptr<void>(e->arena.base, [](void* p) { (void)hipFree(p); });
+    he = hipMemset(e->arena.base, 0, bytes);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
+    he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he)));
+    e->stream = e->own_stream;
+    Arena& A = e->arena;
+    e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
+    e->x = A.take<float>((size_t)e->rows_pad * H);
+    e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
+    e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
+    e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k));
+    if (A.used > A.size) return cleanup(fail(VQ_ERR_STATE, "arena overflow (%zu > %zu)", A.used, A.size));
+    *out = e;
+    return 0;
+}
+
 int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weights, int n_weights, int max_batch,
                            int flags, vq_text_encoder** out) {
     VQ_TRY(require_init());
@@ -540,6 +596,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
     if (he != hipSuccess) { delete e; return fail(VQ_ERR_OOM, "vq_text_encoder_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
     e->arena.size = bytes;
+    e->arena_owner = std::shared_ptr<void>(e->arena.base, [](void* p) { (void)hipFree(p); });
     he = hipMemset(e->arena.base, 0, bytes);
     if (he != hipSuccess) return cleanup(fail(VQ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
     he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -629,7 +686,8 @@ int vq_encoder_destroy(vq_encoder* e) {
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
-    if (e->arena.base) (void)hipFree(e->arena.base);
+    e->arena_owner.reset();          // frees the arena unless a shared handle still reads its weights
+    e->weights_owner.reset();
     for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
     if (e->h_out_stage) (void)hipHostFree(e->h_out_stage);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }

@@ -48,6 +48,7 @@ struct vq_index {
     bool norm_dirty = false, near_unit = true;
     float row_norm_max = 1.0f;
     int scan_version = 2;          // $VQ_AMD_SCAN: 2 = 256x256 phased mainloop (needs dim % 128 == 0), 1 = 128x128
+    bool no_small_scan = false;    // $VQ_AMD_SCAN_SMALL=0: batches of <= 64 queries also take the MFMA-tile scan (A/B switch)
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
@@ -160,9 +161,12 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
 // fp16 MFMA scan + exact re-score with proof; unproven queries go through search_exact.
 int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
     const int64_t n = x->size;
-    const int ver = x->scan_version;                                   // 2: 256x256 phased mainloop, 1: 128x128
-    const int QT = ver == 2 ? SCAN2_QT : SCAN_QT;
-    const int RANGE = ver == 2 ? SCAN2_RANGE : SCAN_RANGE;
+    // small batches (the reference's one-query-at-a-time search, video_search_system.py:297) take the HBM-bound
+    // streaming scan; the 256-query MFMA tile is for batches
+    const bool small = nq <= SCAN3_MAX_Q && (x->dim == 512 || x->dim == 256) && !x->no_small_scan;
+    const int ver = small ? 3 : x->scan_version;                       // 3: streaming, 2: 256x256 phased mainloop, 1: 128x128
+    const int QT = ver == 3 ? SCAN3_QB : ver == 2 ? SCAN2_QT : SCAN_QT;
+    const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver == 2 ? SCAN2_RANGE : SCAN_RANGE;
     const int64_t n_pad = round_up(n, RANGE);
     const int64_t streams = n_pad / SCAN_STREAM_ROWS;
     const int64_t key_budget = (int64_t)1 << 27;                       // 128 Mi (stream,query) pairs = 1 GiB of keys
@@ -198,7 +202,15 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
         {
             Prof p(x, I_MFMA_SCAN);
-            if (ver == 2) {
+            if (ver == 3) {
+                const dim3 grid(cdiv(streams, 4), q_tiles);
+                if (x->dim == 512)
+                    hipLaunchKernelGGL(scan3_f16_top2_kernel<16>, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams,
+                                       q_pad, x->d_keys);
+                else
+                    hipLaunchKernelGGL(scan3_f16_top2_kernel<8>, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams,
+                                       q_pad, x->d_keys);
+            } else if (ver == 2) {
                 const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
                 hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), G2_LDS_BYTES,
                                    x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
@@ -292,6 +304,7 @@ int vq_index_create(int dim, vq_index** out) {
     x->dim = dim;
     if (const char* sv = getenv("VQ_AMD_SCAN")) x->scan_version = atoi(sv) == 1 ? 1 : 2;
     if (dim % 128 != 0) x->scan_version = 1;
+    if (const char* ss = getenv("VQ_AMD_SCAN_SMALL")) x->no_small_scan = atoi(ss) == 0;
     hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete x; return fail(VQ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     x->stream = x->own_stream;

@@ -62,6 +62,18 @@ class VitEncoder:
         self._keep = None          # the library has its own device copies now
         self.output_dim = cfg.proj_dim
 
+    def clone(self, max_batch: Optional[int] = None, concurrent: bool = True) -> "VitEncoder":
+        """Another handle on the SAME device weights (own stream and workspace): what keeping several batches in
+        flight needs (vq_encoder_create_shared).  Either handle may be closed first."""
+        other = object.__new__(VitEncoder)
+        other.compute_dtype, other.cfg, other.device = self.compute_dtype, self.cfg, self.device
+        other.max_batch = int(max_batch or self.max_batch)
+        other._keep, other.output_dim = None, self.output_dim
+        h = c_void_p()
+        _lib.check(_lib.load().vq_encoder_create_shared(self._h, other.max_batch, 2 if concurrent else 0, ctypes.byref(h)))
+        other._h = h
+        return other
+
     # -- host buffers ---------------------------------------------------------
     def encode(self, frames: np.ndarray, swap_rb: bool = True) -> np.ndarray:
         """uint8 [n,S,S,3] → fp32 [n,proj_dim] (synchronous)."""
