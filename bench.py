@@ -409,6 +409,11 @@ def main():
                                                  "bytes_per_pass": matrix_bytes}}
         srch["latency"] = lat
         if rank == 0:
+            for nq_small in (1, 32):                                 # where a small batch's time goes (device side)
+                idx.profile_begin()
+                for _ in range(10):
+                    idx.search_device(q.data_ptr(), nq_small, k, ids.data_ptr(), dd.data_ptr())
+                lat[f"q{nq_small}"]["kernel_ms"] = {k_: v["ms"] / 10 for k_, v in idx.profile_end().items() if v["launches"]}
             idx.profile_begin()
             idx.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
             sp = idx.profile_end()

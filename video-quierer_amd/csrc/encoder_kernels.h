@@ -89,6 +89,88 @@ struct EpiBiasResidualClsF32 {
     }
 };
 
+// ---- LayerNorm folded into the GEMMs around it ---------------------------------------------------------------
+// LN(x)[m][k] = (x[m][k] - mu_m) rstd_m g[k] + b[k], so for the GEMM that consumes it
+//     sum_k LN(x)[m][k] W[n][k] = rstd_m (sum_k x[m][k] W'[n][k]  -  mu_m c1[n])  +  c2[n]
+// with W'[n][k] = g[k] W[n][k] (folded on the host, then rounded to 16 bits), c1[n] = sum_k W'[n][k] (of the ROUNDED
+// weights: what the MFMA really multiplies), c2[n] = sum_k b[k] W[n][k] + bias[n].  The GEMM's A operand is then the
+// raw residual stream rounded to 16 bits (`xh`), which the PRODUCER of x writes next to the fp32 x — the residual
+// epilogues below and the embedding kernels — together with per-row partial sums (sum x, sum x^2) per 64-column
+// granule: ps[granule][row].  No separate LayerNorm pass reads x again (tf:362-383 pre-LN blocks; reference
+// src/core/feature_extractor.py:154).  Rounding x instead of LN(x) to 16 bits has the same relative error per
+// element while |mean| <~ std over the row (true of ViT residual streams, whose rows are dominated by a few large
+// channels of either sign; measured by the layerwise parity tests).
+struct LnPartials { float2* ps; int64_t stride; };     // ps[g * stride + row], g = column / 64
+
+// x += acc + bias (fp32), xh = 16-bit(x), row partials -> ps          (producer: out_proj / fc2)
+template <int SITE, bool F16>
+struct EpiBiasResidualLnF32 {
+    float* x; int ldx; const float* bias; uint16_t* xh; LnPartials part;
+    static constexpr bool kLoads = true, kRowStats = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const { return ld4(x + (size_t)m * ldx + n); }
+    __device__ __forceinline__ void store(int, int, f32x4, f32x4, f32x4) const {}
+    __device__ __forceinline__ f32x4 store_stats(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
+        const f32x4 y = r + v + b;
+        *(f32x4*)(x + (size_t)m * ldx + n) = y;
+        *(uint2*)(xh + (size_t)m * ldx + n) = pack4_h<F16>(y);
+        return y;
+    }
+    __device__ __forceinline__ void put_stats(int m, int n_wave0, float s1, float s2) const {
+        part.ps[(size_t)(n_wave0 >> 6) * part.stride + m] = float2{s1, s2};
+    }
+};
+
+// Last block, CLS rows only: GEMM row m = image m -> residual row m*tokens; xh and the partials are COMPACT (row m)
+template <bool F16>
+struct EpiBiasResidualClsLnF32 {
+    float* x; int hidden; int tokens; const float* bias; int m_valid; uint16_t* xh; LnPartials part;
+    static constexpr bool kLoads = true, kRowStats = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const {
+        return m < m_valid ? ld4(x + (size_t)m * tokens * hidden + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void store(int, int, f32x4, f32x4, f32x4) const {}
+    __device__ __forceinline__ f32x4 store_stats(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
+        const f32x4 y = m < m_valid ? r + v + b : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < m_valid) *(f32x4*)(x + (size_t)m * tokens * hidden + n) = y;
+        *(uint2*)(xh + (size_t)m * hidden + n) = pack4_h<F16>(y);           // padding rows: zeros (finite operands downstream)
+        return y;
+    }
+    __device__ __forceinline__ void put_stats(int m, int n_wave0, float s1, float s2) const {
+        part.ps[(size_t)(n_wave0 >> 6) * part.stride + m] = float2{s1, s2};
+    }
+};
+
+// y = rstd (acc - mu c1) + c2  [quick_gelu]  -> 16-bit                  (consumer: qkv / fc1 on xh)
+template <bool F16, bool GELU>
+struct EpiLnH16 {
+    uint16_t* out; int ldo; const float* c2; const float* c1; LnPartials part; int granules; float inv_h, eps;
+    const float2* lds = nullptr; int m0 = 0;            // bound per workgroup by the kernel (epi_bind_rowstats)
+    static constexpr bool kLoads = false, kRowIn = true;
+    __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(c2 + n); }
+    __device__ __forceinline__ f32x4 aux_at(int n) const { return ld4(c1 + n); }
+    __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void store(int, int, f32x4, f32x4, f32x4) const {}
+    __device__ __forceinline__ float2 make_row_stat(int m) const {          // (mean, rstd) of row m from its partials
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < granules; ++g) { const float2 p = part.ps[(size_t)g * part.stride + m]; s1 += p.x; s2 += p.y; }
+        const float mean = s1 * inv_h;
+        const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
+        return float2{mean, rsqrtf(var + eps)};
+    }
+    __device__ __forceinline__ float2 row_stat(int m) const { return lds[m - m0]; }
+    __device__ __forceinline__ void store_ln(int m, int n, f32x4 v, f32x4 b, f32x4 a, float2 st) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = st.y * (v[i] - st.x * a[i]) + b[i];
+            if constexpr (GELU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * y));
+            v[i] = y;
+        }
+        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
+    }
+};
+
 // Patch-embedding GEMM: GEMM row m = (image b, patch p) -> token row b*T + 1 + p;
 // x = acc + folded_bias + position_embedding[1+p]          (E3)
 struct EpiPatchEmbedF32 {
@@ -205,16 +287,32 @@ void layernorm_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ h
         *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
 }
 
-// Embedding finish (E3 tail + E4 + first LN1): token 0 of every image is
-// class_embedding + position_embedding[0]; then x = pre_layrnorm(x) in place
-// (fp32 residual stream) and h = layer_norm1[layer 0](x) as bf16.
+// The producer side of the folded LayerNorm for kernels that hold a whole row in a wave: xh = 16-bit(x) and the
+// row's partial (sum, sum of squares) per 64-column granule — lane (i, l) holds columns (64 i + l) * 4 .. +3, so the
+// 16 lanes l>>4 == g of register i are granule 4 i + g.
+template <int NV, bool F16>
+__device__ __forceinline__ void emit_xh_and_partials(const float4 (&v)[NV], uint16_t* __restrict__ xh_row, LnPartials part,
+                                                     int row, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        *(uint2*)(xh_row + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+        float s1 = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        float s2 = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((lane & 15) == 0) part.ps[(size_t)(i * 4 + (lane >> 4)) * part.stride + row] = float2{s1, s2};
+    }
+}
+
+// Embedding finish (E3 tail + E4): token 0 of every image is class_embedding + position_embedding[0]; then
+// x = pre_layrnorm(x) in place (fp32 residual stream).  LN1 of layer 0 is folded into the qkv GEMM (EpiLnH16): this
+// kernel is the producer of its operand xh = 16-bit(x) and of the row partials.
 template <int NV, bool F16>
 __global__ __launch_bounds__(256)
-void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
+void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ xh,
                          const float* __restrict__ cls, const float* __restrict__ pos0,
                          const float* __restrict__ g_pre, const float* __restrict__ b_pre,
-                         const float* __restrict__ g_ln1, const float* __restrict__ b_ln1,
-                         int rows, int tokens, float eps) {
+                         LnPartials part, int rows, int tokens, float eps) {
     constexpr int H = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -234,10 +332,7 @@ void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ h,
     ln_row<NV>(v, g_pre, b_pre, lane, eps, H);
 #pragma unroll
     for (int i = 0; i < NV; ++i) *(float4*)(x + (size_t)row * H + (i * 64 + lane) * 4) = v[i];
-    ln_row<NV>(v, g_ln1, b_ln1, lane, eps, H);
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+    emit_xh_and_partials<NV, F16>(v, xh + (size_t)row * H, part, row, lane);
 }
 
 // rows r*stride of a 16-bit [.][cols] matrix -> compact rows r (CLS gather for the last block)
@@ -250,13 +345,12 @@ void gather_rows_h16_kernel(const uint16_t* __restrict__ src, uint16_t* __restri
     }
 }
 
-// ---- text tower embedding (tf:222-256): x = token_embedding[id] + position_embedding[t]; h = LN1(x) ----
+// ---- text tower embedding (tf:222-256): x = token_embedding[id] + position_embedding[t]; xh, partials for the folded LN1 ----
 template <int NV, bool F16>
 __global__ __launch_bounds__(256)
 void embed_tokens_kernel(const int* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
-                         float* __restrict__ x, uint16_t* __restrict__ h,
-                         const float* __restrict__ g_ln1, const float* __restrict__ b_ln1,
-                         int rows, int seq, int vocab, float eps) {
+                         float* __restrict__ x, uint16_t* __restrict__ xh, LnPartials part,
+                         int rows, int seq, int vocab) {
     constexpr int H = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -272,10 +366,7 @@ void embed_tokens_kernel(const int* __restrict__ ids, const float* __restrict__ 
         v[i] = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
         *(float4*)(x + (size_t)row * H + o) = v[i];
     }
-    ln_row<NV>(v, g_ln1, b_ln1, lane, eps, H);
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        *(uint2*)(h + (size_t)row * H + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
+    emit_xh_and_partials<NV, F16>(v, xh + (size_t)row * H, part, row, lane);
 }
 
 // pooling row of every sequence (tf:568-586): first position holding eos_token_id (position 0 if none);

@@ -23,6 +23,7 @@
 // N % 128 == 0, K % 64 == 0, lda/ldw multiples of 8 elements, 16-B aligned bases.
 #pragma once
 #include "vq_common.h"
+#include <type_traits>
 
 namespace vq {
 
@@ -86,6 +87,45 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
 //                                     load->add->store chain per element serialises on the L2 round trip (measured:
 //                                     32 dependent round trips per lane in the residual GEMMs)
 //   void  store(m, n, acc, bias, loaded)
+// Optional functor features (LayerNorm folded into the GEMMs around it, encoder_kernels.h):
+//   kRowStats  the functor's store_stats() returns the values it stored (the new residual row segment); the epilogue
+//              sums them and their squares over the wave's 64 columns and hands the row's partial (sum, sum of squares)
+//              to put_stats(m, n_wave0, s1, s2) — one partial per (row, 64-column granule), no atomics
+//   kRowIn     the functor consumes per-row (mean, rstd) prepared by the kernel prologue (row_stat(m), an LDS read) and a
+//              second per-column constant aux_at(n); its store is store_ln(m, n, acc, bias, aux, stat)
+template <class E, class = void> struct epi_row_stats : std::false_type {};
+template <class E> struct epi_row_stats<E, std::void_t<decltype(E::kRowStats)>> : std::bool_constant<E::kRowStats> {};
+template <class E, class = void> struct epi_row_in : std::false_type {};
+template <class E> struct epi_row_in<E, std::void_t<decltype(E::kRowIn)>> : std::bool_constant<E::kRowIn> {};
+
+template <class Epi>
+__device__ __forceinline__ void epi_emit(const Epi& epi, int m, int n, int n_wave0, int rcol, f32x4 v, f32x4 bias, f32x4 aux, f32x4 loaded) {
+    if constexpr (epi_row_in<Epi>::value) {
+        epi.store_ln(m, n, v, bias, aux, epi.row_stat(m));
+    } else if constexpr (epi_row_stats<Epi>::value) {
+        const f32x4 r = epi.store_stats(m, n, v, bias, loaded);
+        float s1 = (r[0] + r[1]) + (r[2] + r[3]);
+        float s2 = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }     // the 16 lanes of a row: fixed order
+        if (rcol == 0) epi.put_stats(m, n_wave0, s1, s2);
+    } else {
+        epi.store(m, n, v, bias, loaded);
+    }
+}
+
+// kRowIn functors: the workgroup computes (mean, rstd) of its BM tile rows into LDS once (while its first operand
+// tiles are in flight) and binds a private copy of the functor to them.
+template <int BM, class Epi>
+__device__ __forceinline__ Epi epi_bind_rowstats(const Epi& epi, float2* lds_stats, int m0, int tid, int nthreads) {
+    Epi e = epi;
+    if constexpr (epi_row_in<Epi>::value) {
+        for (int r = tid; r < BM; r += nthreads) lds_stats[r] = epi.make_row_stat(m0 + r);
+        e.lds = lds_stats; e.m0 = m0;
+    }
+    return e;
+}
+
 template <int MI, class Epi>      // wave tile = MI*16 rows x 64 cols; acc[mi][ni] = C[16mi + lane&15][16ni + 4(lane>>4) ..+3]
 __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI][4], int m_wave0, int n_wave0,
                                               int lane, const Epi& epi) {
@@ -93,6 +133,8 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
     const int rrow = lane >> 4, rcol = lane & 15;
     const int n = n_wave0 + rcol * 4;
     const f32x4 bias = epi.bias_at(n);
+    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (epi_row_in<Epi>::value) aux = epi.aux_at(n);
     constexpr int FULL = MI / 2;          // passes over 32 rows; an odd MI adds a last pass over 16 rows
     // Epilogues that read memory (residual RMW, position embedding) keep the NEXT pass's reads in flight while the
     // current pass goes through LDS and out: one exposed round trip per tile instead of one per pass (the residual
@@ -123,7 +165,7 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + rrow;
             const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
-            epi.store(m_wave0 + pass * 32 + row, n, v, bias, Epi::kLoads ? loaded[pass & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
+            epi_emit(epi, m_wave0 + pass * 32 + row, n, n_wave0, rcol, v, bias, aux, Epi::kLoads ? loaded[pass & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
     if constexpr (MI & 1) {               // odd block count: a last pass over 16 rows
@@ -135,7 +177,7 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
         for (int it = 0; it < 4; ++it) {
             const int row = it * 4 + rrow;
             const f32x4 v = *(const f32x4*)(strip + row * EPI_ROW_BYTES + rcol * 16);
-            epi.store(m_wave0 + base + row, n, v, bias, Epi::kLoads ? loaded[FULL & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
+            epi_emit(epi, m_wave0 + base + row, n, n_wave0, rcol, v, bias, aux, Epi::kLoads ? loaded[FULL & 1][it] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
 }
@@ -147,7 +189,7 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                     int K, int tiles_n, Epi epi, int m_base) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES + GEMM_BM * 8];     // + (mean, rstd) per tile row (kRowIn)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -202,6 +244,7 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
 
     const int nk = K / GEMM_BK;
     stage(0, 0);
+    const Epi epi_wg = epi_bind_rowstats<GEMM_BM>(epi, (float2*)(smem + GEMM_LDS_BYTES), m0, tid, GEMM_THREADS);
     __syncthreads();          // emits vmcnt(0): the DMA has landed for every wave
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -227,7 +270,7 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
     }
 
     // ---- epilogue (the last __syncthreads() retired every fragment read: LDS is free) ----
-    wave_epilogue<4>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wm * 64, n0 + wn * 64, lane, epi);
+    wave_epilogue<4>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wm * 64, n0 + wn * 64, lane, epi_wg);
 }
 
 template <bool IS_F16, class Epi>

@@ -40,6 +40,8 @@
 
 namespace vq {
 
+constexpr int G2_ROWSTAT_BYTES = G2_BM * 8;      // (mean, rstd) per tile row behind the two K-tile buffers (kRowIn epilogues)
+
 template <bool IS_F16, class Epi, bool CLOCK = false>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
@@ -179,7 +181,10 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
 
     // ---- prologue: tile 0 complete + A0, W0 of tile 1 in flight; A0(0), W0(0) landed ----
     stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
-    if (nk > 1) { stage_a(1, 0, 1); stage_w(1, 0, 1); VQ_VMCNT(8); }
+    if (nk > 1) { stage_a(1, 0, 1); stage_w(1, 0, 1); }
+    // (mean, rstd) of the tile's rows for LayerNorm-consuming epilogues, while the first units are in flight
+    const Epi epi_wg = epi_bind_rowstats<G2_BM>(epi, (float2*)(smem + G2_LDS_BYTES), m0, tid, G2_THREADS);
+    if (nk > 1) { VQ_VMCNT(8); }
     else        { VQ_VMCNT(4); }
     barrier();
 
@@ -200,7 +205,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         if (tid == 0) { clock_out[blockIdx.x * 2] = c1 - c0; clock_out[blockIdx.x * 2 + 1] = r1 - r0; }
     }
 
-    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi_wg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -349,6 +354,8 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                               int M, int N, int K, const Epi& epi) {
+    if constexpr (epi_row_in<Epi>::value) return fail(VQ_ERR_INVALID, "gemm_tn256e: LayerNorm-consuming epilogues run on the 256d / 128 kernels only");
+    else {
     VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
              "gemm_tn256e: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
     VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
@@ -364,6 +371,7 @@ static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const 
                        A, lda, W, ldw, K, tiles_n, epi, gemm_order2d());
     VQ_HIP(hipGetLastError());
     return 0;
+    }
 }
 
 template <bool IS_F16, class Epi>
@@ -376,11 +384,12 @@ static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const 
     static bool attr_set = false;       // per instantiation; one device per process (vq_init)
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<IS_F16, Epi>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + G2_ROWSTAT_BYTES));
         attr_set = true;
     }
     const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
-    hipLaunchKernelGGL((gemm_tn256d_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
+    hipLaunchKernelGGL((gemm_tn256d_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
+                       G2_LDS_BYTES + (epi_row_in<Epi>::value ? G2_ROWSTAT_BYTES : 0), st,
                        A, lda, W, ldw, K, tiles_n, epi, gemm_order2d(), (unsigned long long*)nullptr);
     VQ_HIP(hipGetLastError());
     return 0;

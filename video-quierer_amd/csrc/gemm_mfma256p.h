@@ -297,6 +297,23 @@ static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one 
 template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
+    if constexpr (epi_row_in<Epi>::value) {
+        // epilogues that consume per-row LayerNorm statistics need the kernels with the row-stat prologue
+        const bool fits = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
+        const int64_t tiles = (int64_t)(M / G2_BM) * (N / G2_BN);
+        if (fits && force != 1 && (force == 8 || tiles >= 128)) {
+            const int rem = (int)(tiles % 256);
+            if (force == 0 && gemm_use_tail_split() && tiles > 256 && rem > 0 && rem < 128) {      // thin last round -> 128x128 tiles
+                const int m_main = (int)((tiles - rem) / (N / G2_BN)) * G2_BM;
+                if (m_main > 0 && m_main < M) {
+                    VQ_TRY((launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, m_main, N, K, epi)));
+                    return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
+                }
+            }
+            return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+        }
+        return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    } else {
     const bool allow160 = force != 6;
     if (force == 6) force = 0;
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
@@ -335,6 +352,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     }
     if (fits256 && want256 && force != 1) return launch_gemm_tn256_best<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    }
 }
 
 }  // namespace vq

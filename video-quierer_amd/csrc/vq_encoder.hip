@@ -27,8 +27,10 @@ static const char* kEncClassNames[VQ_ENC_NCLASS] = {
     "patchify_u8", "gemm_patch_embed", "embed_finish_ln", "layernorm_bf16", "gemm_qkv",
     "attention", "gemm_out_proj_residual", "gemm_fc1_quickgelu", "gemm_fc2_residual", "pool_project"};
 
+// LayerNorm 1 / 2 are folded into the qkv / fc1 GEMMs (encoder_kernels.h "LayerNorm folded into the GEMMs"):
+// w_qkv = g1 (.) W_qkv, c1_qkv[n] = sum_k w_qkv[n][k] (of the rounded 16-bit values), c2_qkv[n] = sum_k b1[k] W_qkv[n][k] + bias
 struct LayerW {
-    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_qkv, *b_out, *b_fc1, *b_fc2;
+    float *c1_qkv, *c2_qkv, *b_out, *c1_fc1, *c2_fc1, *b_fc2;
     uint16_t *w_qkv, *w_out, *w_fc1, *w_fc2;
 };
 
@@ -63,7 +65,8 @@ struct vq_encoder {
     // workspace
     uint8_t* d_frames = nullptr;
     float *x = nullptr, *d_out = nullptr;
-    uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;      // h = xh: the residual stream rounded to 16 bits
+    float2* ps = nullptr;                      // LayerNorm row partials [hidden/64][rows_pad]
     uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned staging slots (lazy)
     float* h_out_stage = nullptr;               // pinned result buffer
     // pipelined ingest (vq_encoder_submit_staged / wait_staged): per-slot device frames + pinned results, a copy
@@ -112,11 +115,11 @@ size_t arena_bytes(const vq_vit_config& c, int tokens, int patches, int patch_k,
     add((size_t)h * patch_k * 2); add(h * 4); add(h * 4); add((size_t)tokens * h * 4);
     add(h * 4); add(h * 4); add(h * 4); add(h * 4); add((size_t)c.proj_dim * h * 4);
     for (int l = 0; l < c.layers; ++l) {
-        for (int i = 0; i < 4; ++i) add(h * 4);
-        add(3 * h * 4); add(h * 4); add(m * 4); add(h * 4);
+        add(3 * h * 4); add(3 * h * 4); add(h * 4); add(m * 4); add(m * 4); add(h * 4);
         add(3 * h * h * 2); add(h * h * 2); add(m * h * 2); add(h * m * 2);
     }
     add((size_t)max_batch * c.image_size * c.image_size * 3);
+    add((size_t)(h / 64) * rows_pad * 8);
     add((size_t)rows_pad * h * 4); add((size_t)max_batch * c.proj_dim * 4);
     add((size_t)rows_pad * h * 2); add((size_t)rows_pad * 3 * h * 2); add((size_t)rows_pad * h * 2);
     size_t mlp_elems = std::max((size_t)rows_pad * m, (size_t)prow_pad * patch_k);
@@ -146,6 +149,58 @@ int upload_h16(uint16_t* dst, const float* src, size_t n, bool f16, float scale 
 //   DT_FC2    quick-GELU output x W_fc2
 enum : int { DT_PATCH = 1, DT_QKV = 2, DT_ATTN = 4, DT_FC1 = 8, DT_FC2 = 16, DT_ALL = 31 };
 
+// W' = gamma (.) W (scaled), rounded to the operand type; c1[n] = sum_k W'16[n][k]; c2[n] = scale (sum_k beta[k] W[n][k] + bias[n])
+int upload_folded(uint16_t* dst, float* c1_dst, float* c2_dst, const float* W, const float* gamma, const float* beta,
+                  const float* bias, size_t N, size_t K, bool f16, float scale = 1.0f) {
+    std::vector<uint16_t> w16(N * K);
+    std::vector<float> c1(N), c2(N);
+    for (size_t n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+            const float wf = W[n * K + k] * scale * gamma[k];
+            const uint16_t r = f16 ? __builtin_bit_cast(uint16_t, (_Float16)wf) : f32_to_bf16_rne(wf);
+            w16[n * K + k] = r;
+            s1 += f16 ? (double)(float)__builtin_bit_cast(_Float16, r) : (double)bf16_to_f32(r);
+            s2 += (double)beta[k] * (double)W[n * K + k];
+        }
+        c1[n] = (float)s1;
+        c2[n] = (float)((s2 + (double)bias[n]) * (double)scale);
+    }
+    VQ_HIP(hipMemcpy(dst, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(c1_dst, c1.data(), N * 4, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(c2_dst, c2.data(), N * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// One transformer block's tensors (HF order: ln1.{w,b}, q.{w,b}, k.{w,b}, v.{w,b}, out.{w,b}, ln2.{w,b}, fc1.{w,b}, fc2.{w,b})
+// -> device, with layer_norm1 folded into the fused q|k|v weights (q additionally pre-scaled by d_h^-0.5) and
+// layer_norm2 into fc1.
+int upload_layer(vq_encoder* e, LayerW& L, Arena& A, const float* const* weights, int& wi, size_t H, size_t M, float qscale) {
+    const float *g1 = weights[wi], *b1 = weights[wi + 1];
+    wi += 2;
+    L.w_qkv = A.take<uint16_t>(3 * H * H);
+    L.c1_qkv = A.take<float>(3 * H);
+    L.c2_qkv = A.take<float>(3 * H);
+    for (int part = 0; part < 3; ++part) {        // q, k, v
+        const float s = part == 0 ? qscale : 1.0f;
+        VQ_TRY(upload_folded(L.w_qkv + part * H * H, L.c1_qkv + part * H, L.c2_qkv + part * H, weights[wi], g1, b1, weights[wi + 1],
+                             H, H, e->f16_mask & DT_QKV, s));
+        wi += 2;
+    }
+    L.w_out = A.take<uint16_t>(H * H);    VQ_TRY(upload_h16(L.w_out, weights[wi++], H * H, e->f16_mask & DT_ATTN));
+    L.b_out = A.take<float>(H);           VQ_TRY(upload_f32(L.b_out, weights[wi++], H));
+    const float *g2 = weights[wi], *b2 = weights[wi + 1];
+    wi += 2;
+    L.w_fc1 = A.take<uint16_t>(M * H);
+    L.c1_fc1 = A.take<float>(M);
+    L.c2_fc1 = A.take<float>(M);
+    VQ_TRY(upload_folded(L.w_fc1, L.c1_fc1, L.c2_fc1, weights[wi], g2, b2, weights[wi + 1], M, H, e->f16_mask & DT_FC1));
+    wi += 2;
+    L.w_fc2 = A.take<uint16_t>(H * M);    VQ_TRY(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
+    L.b_fc2 = A.take<float>(H);           VQ_TRY(upload_f32(L.b_fc2, weights[wi++], H));
+    return 0;
+}
+
 template <class Fn> static inline int by_f16(bool f16, Fn&& fn) {
     return f16 ? fn(std::true_type{}) : fn(std::false_type{});
 }
@@ -174,21 +229,16 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     };
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
-    auto layernorm = [&](bool f16, const float* x, uint16_t* h, const float* g, const float* b, int nrows, int stride) {
-        return by_f16(f16, [&](auto F) {
-            hipLaunchKernelGGL((layernorm_bf16_kernel<NV, VQ_F16(F)>), dim3(cdiv(nrows, 4)), dim3(256), 0, st, x, h, g, b, nrows,
-                               c.ln_eps, stride);
-            return 0;
-        });
-    };
+    const LnPartials part{e->ps, e->rows_pad};
+    const int granules = H / 64;
+    const float inv_h = 1.0f / (float)H;
 
     const int nl = e->run_layers < 0 ? c.layers : std::min(e->run_layers, c.layers);
     if (e->is_text) {
         Prof p(e, C_EMBED_FINISH);
-        const LayerW& L0 = e->layers[0];
         by_f16(fQ, [&](auto F) {
             hipLaunchKernelGGL((embed_tokens_kernel<NV, VQ_F16(F)>), dim3(cdiv(rows, 4)), dim3(256), 0, st, d_ids, e->tok_emb,
-                               e->pos, e->x, e->h, L0.ln1_g, L0.ln1_b, rows, T, e->vocab, c.ln_eps);
+                               e->pos, e->x, e->h, part, rows, T, e->vocab);
             return 0;
         });
         hipLaunchKernelGGL(eos_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_ids, e->d_rowidx, n, T, e->eos_id);
@@ -217,12 +267,11 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                                                EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force);
         }));
     }
-    {   // CLS row, pre_layrnorm (in place), LN1 of layer 0
+    {   // CLS row, pre_layrnorm (in place); xh + row partials for the LN1 folded into layer 0's qkv GEMM
         Prof p(e, C_EMBED_FINISH);
-        const LayerW& L0 = e->layers[0];
         by_f16(fQ, [&](auto F) {
             hipLaunchKernelGGL((embed_finish_kernel<NV, VQ_F16(F)>), dim3(cdiv(rows, 4)), dim3(256), 0, st, e->x, e->h, e->cls,
-                               e->pos, e->pre_g, e->pre_b, L0.ln1_g, L0.ln1_b, rows, T, c.ln_eps);
+                               e->pos, e->pre_g, e->pre_b, part, rows, T, c.ln_eps);
             return 0;
         });
     }
@@ -230,17 +279,13 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     e->h_is_f16 = fQ;
     for (int l = 0; l < nl; ++l) {
         const LayerW& L = e->layers[l];
-        if (l > 0) {
-            Prof p(e, C_LAYERNORM);
-            layernorm(fQ, e->x, e->h, L.ln1_g, L.ln1_b, rows, 1);
-            e->h_is_f16 = fQ;
-        }
-        {   // E6: fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights)
+        {   // E5/E6: LN1 (folded) + fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights) on xh
             Prof p(e, C_GEMM_QKV);
             VQ_TRY(by_f16(fQ, [&](auto F) {
                 return by_f16(fA, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_qkv, H, gemm_rows(3 * H, H), 3 * H, H,
-                                                       EpiBiasH16<VQ_F16(FO)>{e->qkv, 3 * H, L.b_qkv}, e->gemm_force);
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
+                                                       EpiLnH16<VQ_F16(FO), false>{e->qkv, 3 * H, L.c2_qkv, L.c1_qkv, part, granules, inv_h, c.ln_eps},
+                                                       e->gemm_force);
                 });
             }));
         }
@@ -275,25 +320,24 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         const bool cls_only = !e->is_text && e->prune_last && e->run_layers < 0 && l == c.layers - 1;   // debug runs keep every row
         if (cls_only) {
             const int crows = pad_rows(n);
-            {
+            {   // attention rows of the CLS tokens -> compact operand (the q|k|v buffer is free now); x, xh (compact) out
                 Prof p(e, C_GEMM_OUT);
-                hipLaunchKernelGGL(gather_rows_h16_kernel, dim3(cdiv(n * (H / 8), 256)), dim3(256), 0, st, e->att, e->h, n, H, T);
-                e->h_is_f16 = fA;
+                hipLaunchKernelGGL(gather_rows_h16_kernel, dim3(cdiv(n * (H / 8), 256)), dim3(256), 0, st, e->att, e->qkv, n, H, T);
                 VQ_TRY(by_f16(fA, [&](auto F) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_out, H, crows, H, H,
-                                                       EpiBiasResidualClsF32{e->x, H, T, L.b_out, n}, e->gemm_force);
+                    return by_f16(f1, [&](auto FO) {
+                        return launch_gemm_auto<VQ_F16(F)>(st, e->qkv, H, L.w_out, H, crows, H, H,
+                                                           EpiBiasResidualClsLnF32<VQ_F16(FO)>{e->x, H, T, L.b_out, n, e->h, part}, e->gemm_force);
+                    });
                 }));
-            }
-            {
-                Prof p(e, C_LAYERNORM);
-                layernorm(f1, e->x, e->att, L.ln2_g, L.ln2_b, n, T);
+                e->h_is_f16 = f1;
             }
             {
                 Prof p(e, C_GEMM_FC1);
                 VQ_TRY(by_f16(f1, [&](auto F) {
                     return by_f16(f2, [&](auto FO) {
-                        return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_fc1, H, crows, c.mlp, H,
-                                                           EpiBiasQuickGeluH16<VQ_F16(FO)>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force);
+                        return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_fc1, H, crows, c.mlp, H,
+                                                           EpiLnH16<VQ_F16(FO), true>{e->mlp, c.mlp, L.c2_fc1, L.c1_fc1, part, granules, inv_h, c.ln_eps},
+                                                           e->gemm_force);
                     });
                 }));
             }
@@ -306,33 +350,35 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
             }
             continue;
         }
-        {
+        {   // out_proj + residual; writes xh and the row partials for the LN2 folded into fc1
             Prof p(e, C_GEMM_OUT);
             VQ_TRY(by_f16(fA, [&](auto F) {
-                return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
-                                                   EpiBiasResidualF32<0>{e->x, H, L.b_out}, e->gemm_force);
+                return by_f16(f1, [&](auto FO) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
+                                                       EpiBiasResidualLnF32<0, VQ_F16(FO)>{e->x, H, L.b_out, e->h, part}, e->gemm_force);
+                });
             }));
-        }
-        {
-            Prof p(e, C_LAYERNORM);
-            layernorm(f1, e->x, e->h, L.ln2_g, L.ln2_b, rows, 1);
             e->h_is_f16 = f1;
         }
-        {   // E7: fc1 + quick_gelu
+        {   // E7: LN2 (folded) + fc1 + quick_gelu on xh
             Prof p(e, C_GEMM_FC1);
             VQ_TRY(by_f16(f1, [&](auto F) {
                 return by_f16(f2, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_fc1, H, gemm_rows(c.mlp, H), c.mlp, H,
-                                                       EpiBiasQuickGeluH16<VQ_F16(FO)>{e->mlp, c.mlp, L.b_fc1}, e->gemm_force);
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
+                                                       EpiLnH16<VQ_F16(FO), true>{e->mlp, c.mlp, L.c2_fc1, L.c1_fc1, part, granules, inv_h, c.ln_eps},
+                                                       e->gemm_force);
                 });
             }));
         }
-        {
+        {   // fc2 + residual; writes xh and the row partials for the next block's folded LN1
             Prof p(e, C_GEMM_FC2);
             VQ_TRY(by_f16(f2, [&](auto F) {
-                return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
-                                                   EpiBiasResidualF32<1>{e->x, H, L.b_fc2}, e->gemm_force);
+                return by_f16(fQ, [&](auto FO) {
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
+                                                       EpiBiasResidualLnF32<1, VQ_F16(FO)>{e->x, H, L.b_fc2, e->h, part}, e->gemm_force);
+                });
             }));
+            e->h_is_f16 = fQ;
         }
     }
     {   // E8-E10
@@ -456,28 +502,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     e->pre_b = A.take<float>(H);              UP(upload_f32(e->pre_b, weights[wi++], H));
     e->layers.resize(c.layers);
     const float qscale = 1.0f / std::sqrt((float)(c.hidden / c.heads));   // 0.125: exact in bf16
-    for (int l = 0; l < c.layers; ++l) {
-        LayerW& L = e->layers[l];
-        L.ln1_g = A.take<float>(H);           UP(upload_f32(L.ln1_g, weights[wi++], H));
-        L.ln1_b = A.take<float>(H);           UP(upload_f32(L.ln1_b, weights[wi++], H));
-        L.w_qkv = A.take<uint16_t>(3 * H * H);
-        L.b_qkv = A.take<float>(3 * H);
-        for (int part = 0; part < 3; ++part) {        // q, k, v
-            const float s = part == 0 ? qscale : 1.0f;
-            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->f16_mask & DT_QKV, s));
-            std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
-            for (auto& v : b) v *= s;
-            UP(upload_f32(L.b_qkv + part * H, b.data(), H));
-        }
-        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->f16_mask & DT_ATTN));
-        L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
-        L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
-        L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
-        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->f16_mask & DT_FC1));
-        L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
-        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
-        L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
-    }
+    for (int l = 0; l < c.layers; ++l) UP(upload_layer(e, e->layers[l], A, weights, wi, H, M, qscale));
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));
     e->post_b = A.take<float>(H);             UP(upload_f32(e->post_b, weights[wi++], H));
     e->w_proj = A.take<float>((size_t)c.proj_dim * H);
@@ -491,6 +516,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
 #undef UP
     // workspace
     e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
+    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
@@ -528,6 +554,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     size_t bytes = 0;
     auto add = [&](size_t b) { bytes = ((bytes + 255) & ~(size_t)255) + b; };
     add((size_t)max_batch * c.image_size * c.image_size * 3);
+    add((size_t)(H / 64) * e->rows_pad * 8);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * c.proj_dim * 4);
     add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
     add(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k) * 2);
@@ -543,6 +570,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->stream = e->own_stream;
     Arena& A = e->arena;
     e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
+    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
@@ -584,10 +612,10 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     auto add = [&](size_t b) { bytes = ((bytes + 255) & ~(size_t)255) + b; };
     add((size_t)t.vocab * H * 4); add(T * H * 4); add(H * 4); add(H * 4); add((size_t)t.proj_dim * H * 4);
     for (int l = 0; l < t.layers; ++l) {
-        for (int i = 0; i < 4; ++i) add(H * 4);
-        add(3 * H * 4); add(H * 4); add(M * 4); add(H * 4);
+        add(3 * H * 4); add(3 * H * 4); add(H * 4); add(M * 4); add(M * 4); add(H * 4);
         add(3 * H * H * 2); add(H * H * 2); add(M * H * 2); add(H * M * 2);
     }
+    add((size_t)(H / 64) * e->rows_pad * 8);
     add((size_t)max_batch * T * 4); add((size_t)max_batch * 4);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * t.proj_dim * 4);
     add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
@@ -610,28 +638,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->pos = A.take<float>(T * H);                      UP(upload_f32(e->pos, weights[wi++], T * H));
     e->layers.resize(t.layers);
     const float qscale = 1.0f / std::sqrt((float)(t.hidden / t.heads));
-    for (int l = 0; l < t.layers; ++l) {
-        LayerW& L = e->layers[l];
-        L.ln1_g = A.take<float>(H);           UP(upload_f32(L.ln1_g, weights[wi++], H));
-        L.ln1_b = A.take<float>(H);           UP(upload_f32(L.ln1_b, weights[wi++], H));
-        L.w_qkv = A.take<uint16_t>(3 * H * H);
-        L.b_qkv = A.take<float>(3 * H);
-        for (int part = 0; part < 3; ++part) {
-            const float sc = part == 0 ? qscale : 1.0f;
-            UP(upload_h16(L.w_qkv + part * H * H, weights[wi++], H * H, e->f16_mask & DT_QKV, sc));
-            std::vector<float> b(weights[wi], weights[wi] + H); ++wi;
-            for (auto& v : b) v *= sc;
-            UP(upload_f32(L.b_qkv + part * H, b.data(), H));
-        }
-        L.w_out = A.take<uint16_t>(H * H);    UP(upload_h16(L.w_out, weights[wi++], H * H, e->f16_mask & DT_ATTN));
-        L.b_out = A.take<float>(H);           UP(upload_f32(L.b_out, weights[wi++], H));
-        L.ln2_g = A.take<float>(H);           UP(upload_f32(L.ln2_g, weights[wi++], H));
-        L.ln2_b = A.take<float>(H);           UP(upload_f32(L.ln2_b, weights[wi++], H));
-        L.w_fc1 = A.take<uint16_t>(M * H);    UP(upload_h16(L.w_fc1, weights[wi++], M * H, e->f16_mask & DT_FC1));
-        L.b_fc1 = A.take<float>(M);           UP(upload_f32(L.b_fc1, weights[wi++], M));
-        L.w_fc2 = A.take<uint16_t>(H * M);    UP(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
-        L.b_fc2 = A.take<float>(H);           UP(upload_f32(L.b_fc2, weights[wi++], H));
-    }
+    for (int l = 0; l < t.layers; ++l) UP(upload_layer(e, e->layers[l], A, weights, wi, H, M, qscale));
     e->post_g = A.take<float>(H);             UP(upload_f32(e->post_g, weights[wi++], H));     // final_layer_norm
     e->post_b = A.take<float>(H);             UP(upload_f32(e->post_b, weights[wi++], H));
     e->w_proj = A.take<float>((size_t)t.proj_dim * H);
@@ -645,6 +652,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
 #undef UP
     e->d_ids = A.take<int>((size_t)max_batch * T);
     e->d_rowidx = A.take<int>(max_batch);
+    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * t.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
