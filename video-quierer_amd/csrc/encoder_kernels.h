@@ -100,7 +100,8 @@ struct EpiBiasResidualClsF32 {
 // src/core/feature_extractor.py:154).  Rounding x instead of LN(x) to 16 bits has the same relative error per
 // element while |mean| <~ std over the row (true of ViT residual streams, whose rows are dominated by a few large
 // channels of either sign; measured by the layerwise parity tests).
-struct LnPartials { float2* ps; int64_t stride; };     // ps[g * stride + row], g = column / 64
+constexpr int LN_MAX_GRANULES = 16;                     // hidden <= 1024
+struct LnPartials { float2* ps; int64_t stride; };     // ps[g * stride + row], g = column / 64; LN_MAX_GRANULES planes, unused ones stay zero
 
 // x += acc + bias (fp32), xh = 16-bit(x), row partials -> ps          (producer: out_proj / fc2)
 template <int SITE, bool F16>
@@ -153,8 +154,15 @@ struct EpiLnH16 {
     __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ void store(int, int, f32x4, f32x4, f32x4) const {}
     __device__ __forceinline__ float2 make_row_stat(int m) const {          // (mean, rstd) of row m from its partials
+        // all LN_MAX_GRANULES loads are issued before the first add (the buffer always has that many granule planes,
+        // the unused ones zero): a loop with a run-time bound costs one exposed round trip per granule here, because
+        // the workgroup's LDS-DMA prologue is in flight and the compiler drains the queue at every use of a load
+        float2 p[LN_MAX_GRANULES];
+#pragma unroll
+        for (int g = 0; g < LN_MAX_GRANULES; ++g) p[g] = part.ps[(size_t)g * part.stride + m];
         float s1 = 0.f, s2 = 0.f;
-        for (int g = 0; g < granules; ++g) { const float2 p = part.ps[(size_t)g * part.stride + m]; s1 += p.x; s2 += p.y; }
+#pragma unroll
+        for (int g = 0; g < LN_MAX_GRANULES; ++g) { s1 += p[g].x; s2 += p[g].y; }
         const float mean = s1 * inv_h;
         const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
         return float2{mean, rsqrtf(var + eps)};

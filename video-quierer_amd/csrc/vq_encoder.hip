@@ -119,7 +119,7 @@ size_t arena_bytes(const vq_vit_config& c, int tokens, int patches, int patch_k,
         add(3 * h * h * 2); add(h * h * 2); add(m * h * 2); add(h * m * 2);
     }
     add((size_t)max_batch * c.image_size * c.image_size * 3);
-    add((size_t)(h / 64) * rows_pad * 8);
+    add((size_t)LN_MAX_GRANULES * rows_pad * 8);
     add((size_t)rows_pad * h * 4); add((size_t)max_batch * c.proj_dim * 4);
     add((size_t)rows_pad * h * 2); add((size_t)rows_pad * 3 * h * 2); add((size_t)rows_pad * h * 2);
     size_t mlp_elems = std::max((size_t)rows_pad * m, (size_t)prow_pad * patch_k);
@@ -516,7 +516,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
 #undef UP
     // workspace
     e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
-    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
+    e->ps = A.take<float2>((size_t)LN_MAX_GRANULES * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
@@ -554,7 +554,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     size_t bytes = 0;
     auto add = [&](size_t b) { bytes = ((bytes + 255) & ~(size_t)255) + b; };
     add((size_t)max_batch * c.image_size * c.image_size * 3);
-    add((size_t)(H / 64) * e->rows_pad * 8);
+    add((size_t)LN_MAX_GRANULES * e->rows_pad * 8);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * c.proj_dim * 4);
     add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
     add(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k) * 2);
@@ -570,7 +570,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->stream = e->own_stream;
     Arena& A = e->arena;
     e->d_frames = A.take<uint8_t>((size_t)max_batch * c.image_size * c.image_size * 3);
-    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
+    e->ps = A.take<float2>((size_t)LN_MAX_GRANULES * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
@@ -615,7 +615,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
         add(3 * H * 4); add(3 * H * 4); add(H * 4); add(M * 4); add(M * 4); add(H * 4);
         add(3 * H * H * 2); add(H * H * 2); add(M * H * 2); add(H * M * 2);
     }
-    add((size_t)(H / 64) * e->rows_pad * 8);
+    add((size_t)LN_MAX_GRANULES * e->rows_pad * 8);
     add((size_t)max_batch * T * 4); add((size_t)max_batch * 4);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * t.proj_dim * 4);
     add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
@@ -652,7 +652,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
 #undef UP
     e->d_ids = A.take<int>((size_t)max_batch * T);
     e->d_rowidx = A.take<int>(max_batch);
-    e->ps = A.take<float2>((size_t)(H / 64) * e->rows_pad);
+    e->ps = A.take<float2>((size_t)LN_MAX_GRANULES * e->rows_pad);
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * t.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
