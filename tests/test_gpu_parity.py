@@ -288,6 +288,7 @@ def test_index_edge_cases(gpu_lib, tmp_path):
         OptimizedHNSWIndex(dimension=64).load(path)
     with pytest.raises(ValueError):
         idx.search(np.zeros(32, np.float32), 1)                       # wrong dimension
+    assert idx.search(vecs[0], 0) == [] and idx.search_batch([vecs[0], vecs[1]], 0) == [[], []]      # k = 0: reference slices [:0]
 
 
 def test_index_device_normalise_matches_oracle(gpu_lib):

@@ -171,6 +171,8 @@ class HNSWIndex:
         if unit.shape[1] != self.dimension:
             raise ValueError(f"query dimension {unit.shape[1]} != index dimension {self.dimension}")
         kk = min(k, n)
+        if kk <= 0:
+            return [[] for _ in queries]          # reference: sorted(candidates)[:0] == [] (hnsw.py:269)
         if self._identity:
             ids, dist = self._raw_search(unit, kk)
             return [[{"id": int(i), "distance": d, "score": np.float32(1.0) - d} for i, d in zip(ri, rd) if i >= 0]
@@ -231,6 +233,10 @@ class HNSWIndex:
 
     # -- persistence (reference :306-380: pickle + sha256 sidecar) ------------------
     def save(self, filepath: str) -> None:
+        """Reference :306-339: same pickle keys, HIGHEST_PROTOCOL, SHA-256 sidecar.  The index is exact, so ``levels``
+        and ``graph`` are flat: the reference class LOADS such a file (same rows, ids and parameters) but its graph
+        walk has nothing to walk — a reference user re-adds the rows; files written by the
+        reference load here and answer as the reference does.  The extra key ``exact_index`` marks files from here."""
         with self.lock:
             save_data = {
                 "dimension": self.dimension, "M": self.M, "max_M": self.max_M,
@@ -251,6 +257,9 @@ class HNSWIndex:
                 f.write(checksum)
 
     def load(self, filepath: str) -> None:
+        """Reference :341-380 (checksum check, missing sidecar tolerated, ValueError on mismatch).  Only ``data`` (and
+        the parameters) are used; the rows are stored as given and MEASURED by the library (vq_index_add
+        normalize=0): a file whose rows are not unit-norm still searches exactly, on the fp32 scan."""
         try:
             with open(filepath, "rb") as f:
                 current = hashlib.sha256(f.read()).hexdigest()
