@@ -625,6 +625,206 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (nq <= SCAN3_MAX_Q, keys in layout 3): ONE workgroup per query instead of 16 queries per workgroup.
+// rescore_verify_kernel walks streams/16 keys per thread (488 dependent steps at 1M rows: 0.26 ms for a single
+// query, more than the HBM-bound scan in front of it); here the 256 threads of a workgroup split one query's
+// streams 256 ways (31 steps at 1M rows).  Same proof, same outcome codes, same exact arithmetic:
+//   1. thread t keeps the best RS_KEEP keys of streams t, t+256, ...; whatever it drops is bounded by `dropped`
+//   2. the best RV_C of the 256*RS_KEEP kept keys: rank counting inside each wave (256 keys -> 32), then over the
+//      4*32 survivors; the best key NOT selected bounds every kept-but-unselected key
+//   3. exact fp64-chain re-score of the RV_C candidates from the fp32 master (one thread per candidate)
+//   4. k-th best exact score s_k; every bound + eps must lie below it; a stream whose 2nd key could still matter
+//      is re-scored in full (<= RV_RESCAN_MAX), its candidates dropped from the pool (no duplicates)
+//   5. exact top-k of the pool by (distance, row): rank counting
+constexpr int RS_KEEP = 4;
+
+__global__ __launch_bounds__(256)
+void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
+                                 const float* __restrict__ rows, int64_t n_valid, int dim,
+                                 const float* __restrict__ queries, int nq, int k,
+                                 int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
+                                 int32_t* __restrict__ flags, float eps_rows) {
+    __shared__ float kept_v[256 * RS_KEEP];
+    __shared__ int kept_s[256 * RS_KEEP];
+    __shared__ float sel_v[4 * RV_C];
+    __shared__ int sel_s[4 * RV_C];
+    __shared__ float wave_floor[4];
+    __shared__ float red[256];
+    __shared__ float cand_key[RV_C];
+    __shared__ int cand_src[RV_C];
+    __shared__ int cand_row[RV_POOL];
+    __shared__ float cand_dist[RV_POOL];
+    __shared__ float bound_rest_s, floor_max_s, qnorm2_s;
+    __shared__ int resc_stream[RV_RESCAN_MAX];
+    __shared__ int resc_n, state, pool_n;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const float NEG = -__builtin_inff();
+    const float* qv = queries + (size_t)q * dim;
+
+    // ---- 1. per-thread top RS_KEEP of its streams ----
+    float kv[RS_KEEP]; int ksrc[RS_KEEP];
+#pragma unroll
+    for (int i = 0; i < RS_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
+    float dropped = NEG;
+    auto offer = [&](float v, int src) __attribute__((always_inline)) {
+        if (v > kv[RS_KEEP - 1]) {
+            dropped = fmaxf(dropped, kv[RS_KEEP - 1]);
+#pragma unroll
+            for (int i = 0; i < RS_KEEP; ++i) {
+                if (v > kv[i]) { const float tv = kv[i]; const int ts = ksrc[i]; kv[i] = v; ksrc[i] = src; v = tv; src = ts; }
+            }
+        } else {
+            dropped = fmaxf(dropped, v);
+        }
+    };
+    constexpr int PF = 8;
+    int64_t s = tid;
+    for (; s + (PF - 1) * 256 < streams; s += PF * 256) {
+        uint2 two[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + ((size_t)(s + u * 256) * q_pad + q) * 2);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int src = (int)((s + u * 256) * 2);
+            offer(__builtin_bit_cast(float, two[u].x), src);
+            offer(__builtin_bit_cast(float, two[u].y), src + 1);
+        }
+    }
+    for (; s < streams; s += 256) {
+        const uint2 two = *(const uint2*)(keys + ((size_t)s * q_pad + q) * 2);
+        offer(__builtin_bit_cast(float, two.x), (int)(s * 2));
+        offer(__builtin_bit_cast(float, two.y), (int)(s * 2 + 1));
+    }
+#pragma unroll
+    for (int i = 0; i < RS_KEEP; ++i) { kept_v[tid * RS_KEEP + i] = kv[i]; kept_s[tid * RS_KEEP + i] = ksrc[i]; }
+    {   // |q|^2 and the largest dropped key: block reductions through `red`
+        float s2 = 0.f;
+        for (int i = tid; i < dim; i += 256) s2 += qv[i] * qv[i];
+        red[tid] = s2;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int i = 0; i < 256; ++i) t += red[i]; qnorm2_s = t; }
+        __syncthreads();
+        red[tid] = dropped;
+        __syncthreads();
+        if (tid == 0) { float t = NEG; for (int i = 0; i < 256; ++i) t = fmaxf(t, red[i]); floor_max_s = t; resc_n = 0; state = 0; }
+    }
+    __syncthreads();
+
+    // ---- 2a. each wave: the best RV_C of its 64*RS_KEEP keys (rank = number of better keys, index breaks ties) ----
+    {
+        const int base = wave * 64 * RS_KEEP;
+#pragma unroll
+        for (int i = 0; i < RS_KEEP; ++i) {
+            const int me = lane * RS_KEEP + i;
+            const float vi = kept_v[base + me];
+            int rank = 0;
+            for (int j = 0; j < 64 * RS_KEEP; ++j) {
+                const float vj = kept_v[base + j];
+                rank += (vj > vi) || (vj == vi && j < me);
+            }
+            if (rank < RV_C) { sel_v[wave * RV_C + rank] = vi; sel_s[wave * RV_C + rank] = kept_s[base + me]; }
+            if (rank == RV_C) wave_floor[wave] = vi;
+        }
+    }
+    __syncthreads();
+    // ---- 2b. the best RV_C of the 4*RV_C survivors ----
+    if (tid < 4 * RV_C) {
+        const float vi = sel_v[tid];
+        int rank = 0;
+        for (int j = 0; j < 4 * RV_C; ++j) {
+            const float vj = sel_v[j];
+            rank += (vj > vi) || (vj == vi && j < tid);
+        }
+        if (rank < RV_C) { cand_key[rank] = vi; cand_src[rank] = sel_s[tid]; }
+        if (rank == RV_C) bound_rest_s = fmaxf(fmaxf(vi, fmaxf(wave_floor[0], wave_floor[1])), fmaxf(wave_floor[2], wave_floor[3]));
+    }
+    __syncthreads();
+
+    // ---- 3. exact re-score of the candidates ----
+    if (tid < RV_C) {
+        const int src = cand_src[tid];
+        int row = -1; float d = __builtin_inff();
+        if (src >= 0 && cand_key[tid] > NEG) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[tid]);
+            const int64_t r = scan3_row_of(src >> 1, (int)(kb & 127u));
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+        }
+        cand_row[tid] = row; cand_dist[tid] = d;
+    }
+    __syncthreads();
+
+    // ---- 4. which bounds are still open? ----
+    if (tid == 0) {
+        const int kk = k < RV_C ? k : RV_C;
+        float dk = __builtin_inff(); int have = 0;
+        for (int i = 0; i < RV_C; ++i) have += cand_row[i] >= 0;
+        if (have >= kk) {
+            for (int i = 0; i < RV_C; ++i) {
+                if (cand_row[i] < 0) continue;
+                int rank = 0;
+                for (int j = 0; j < RV_C; ++j)
+                    rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < dist_key(cand_dist[i], (uint32_t)cand_row[i]);
+                if (rank == kk - 1) dk = cand_dist[i];
+            }
+        }
+        const float sk = 1.0f - dk;
+        const float eps = eps_rows * sqrtf(qnorm2_s);          // NaN for a non-finite query: every test fails -> exact fallback
+        int st = 0, nres = 0;
+        if (have < kk) st = 2;
+        else {
+            if (!(bound_rest_s + eps < sk)) st = 2;            // a kept key outside the best C could still matter
+            if (!(floor_max_s + eps < sk)) st = 2;             // a thread dropped a key that could matter
+            if (st == 0) {
+                for (int c = 0; c < RV_C; ++c) {
+                    if ((cand_src[c] & 1) && cand_key[c] + eps >= sk) {      // the stream's 2nd key: its unseen rows are bounded only by it
+                        if (nres < RV_RESCAN_MAX) resc_stream[nres++] = cand_src[c] >> 1; else st = 2;
+                    }
+                }
+                if (st == 0 && nres > 0) st = 1;
+            }
+        }
+        state = st; resc_n = st == 1 ? nres : 0;
+    }
+    __syncthreads();
+
+    // ---- 5. stream rescans (all 128 rows, exactly); candidates of a rescanned stream leave the pool ----
+    const int nres = resc_n;
+    if (nres > 0) {
+        if (tid < RV_C && cand_row[tid] >= 0) {
+            for (int w = 0; w < nres; ++w) if ((cand_src[tid] >> 1) == resc_stream[w]) cand_row[tid] = -1;
+        }
+        for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
+            const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
+            const int64_t r = scan3_row_of(resc_stream[which], local);
+            int row = -1; float d = __builtin_inff();
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+            cand_row[RV_C + i] = row; cand_dist[RV_C + i] = d;
+        }
+    }
+    if (tid == 0) pool_n = RV_C + nres * SCAN_STREAM_ROWS;
+    __syncthreads();
+
+    // ---- 6. exact top-k of the pool: rank by (distance, row); rows are distinct, so ranks are a permutation ----
+    {
+        const int pn = pool_n;
+        if (tid == 0) flags[q] = state;
+        for (int j = tid; j < k; j += 256) { out_ids[(size_t)q * k + j] = -1; out_dist[(size_t)q * k + j] = __builtin_inff(); }
+        __syncthreads();
+        for (int i = tid; i < pn; i += 256) {
+            if (cand_row[i] < 0) continue;
+            const uint64_t ki = dist_key(cand_dist[i], (uint32_t)cand_row[i]);
+            int rank = 0;
+            for (int j = 0; j < pn; ++j)
+                rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
+            if (rank < k) { out_ids[(size_t)q * k + rank] = cand_row[i]; out_dist[(size_t)q * k + rank] = cand_dist[i]; }
+        }
+    }
+}
+
 // Copies the exact-scan results of the flagged queries over the fast-path results.
 __global__ void patch_results_kernel(const int32_t* __restrict__ slot_query, int nslots, int k,
                                      const int32_t* __restrict__ ex_ids, const float* __restrict__ ex_dist,

@@ -221,6 +221,11 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
         {
             Prof p(x, I_RESCORE);
+            if (ver == 3)
+                hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_keys, streams, q_pad, x->rows, n,
+                                   x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
+                                   scan_eps_unit(x->dim) * x->row_norm_max);
+            else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
                                d_dist_out + q0 * k, x->d_flags + q0, ver, scan_eps_unit(x->dim) * x->row_norm_max);
