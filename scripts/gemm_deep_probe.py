@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the 256x256 mainloops in ONE process, interleaved rounds (cdna_hip_programming.md rule 24):
 kernel 2 = four-phase (prefetch 1-3 phases ahead), 8 = four-phase with the deep prefetch (5-6 phases ahead),
-9 = the deep prefetch with two 32-MFMA phases per K-tile, 5 = 160x256 ring.  Plain fp32-store epilogue, random data.  Then the clock held inside kernel 8's K loop."""
+10 = 32-wide ring with register double-buffered fragments and one barrier per sub-tile, 5 = 160x256 ring.  Plain fp32-store epilogue, random data.  Then the clock held inside kernel 8's K loop."""
 import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ def run(m, n, k, kernel, reps=20):
     return ms.value
 shapes = [(8192, 8192, 8192), (16384, 4096, 4096), (12800, 3072, 768), (12800, 2304, 768), (12800, 768, 3072), (12800, 768, 768)]
 for (m, n, k) in shapes:
-    res = {2: [], 8: [], 9: []}
+    res = {8: [], 10: []}
     if m % 160 == 0 and n == 768:
         res[5] = []
     for rnd in range(5):

@@ -25,6 +25,7 @@
 #include "gemm_mfma160.h"
 #include "gemm_mfma256w4.h"
 #include "gemm_mfma256d.h"
+#include "gemm_mfma256f.h"
 
 namespace vq {
 
@@ -327,6 +328,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 9) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 2) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
 #ifdef VQ_GEMM_EXPERIMENTS

@@ -744,16 +744,36 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
     __syncthreads();
 
-    // ---- 3. exact re-score of the candidates ----
+    // ---- 3. exact re-score of the candidates: the RV_C rows (and the query) are staged into LDS by all 256 threads
+    //         in one round of wide loads — a thread walking its own 2-KiB row straight from HBM pays one exposed
+    //         round trip per 16 bytes — then one thread per candidate runs the fixed-order fp64 chain out of LDS ----
     if (tid < RV_C) {
         const int src = cand_src[tid];
-        int row = -1; float d = __builtin_inff();
+        int row = -1;
         if (src >= 0 && cand_key[tid] > NEG) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[tid]);
             const int64_t r = scan3_row_of(src >> 1, (int)(kb & 127u));
-            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+            if (r < n_valid) row = (int)r;
         }
-        cand_row[tid] = row; cand_dist[tid] = d;
+        cand_row[tid] = row;
+    }
+    __syncthreads();
+    {
+        extern __shared__ __attribute__((aligned(16))) float rs_dyn[];        // [RV_C][dim + 4] rows, then [dim] query
+        const int ldr = dim + 4, d4 = dim >> 2;                                // +4 floats: rows on different LDS banks
+        float* qbuf = rs_dyn + RV_C * ldr;
+        for (int i = tid; i < RV_C * d4; i += 256) {
+            const int c = i / d4, j = i - c * d4;
+            const int r = cand_row[c];
+            if (r >= 0) *(float4*)(rs_dyn + c * ldr + 4 * j) = *(const float4*)(rows + (size_t)r * dim + 4 * j);
+        }
+        for (int i = tid; i < d4; i += 256) *(float4*)(qbuf + 4 * i) = *(const float4*)(qv + 4 * i);
+        __syncthreads();
+        if (tid < RV_C) {
+            float d = __builtin_inff();
+            if (cand_row[tid] >= 0) d = 1.0f - exact_dot_chain(rs_dyn + tid * ldr, qbuf, dim);
+            cand_dist[tid] = d;
+        }
     }
     __syncthreads();
 

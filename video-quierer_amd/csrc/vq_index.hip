@@ -182,6 +182,14 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         x->hflags_cap = round_up(nq, 1024);
     }
     const int ranges = (int)(n_pad / RANGE);
+    if (ver == 3) {
+        static bool attr3_set = false;
+        if (!attr3_set) {
+            VQ_HIP(hipFuncSetAttribute((const void*)rescore_verify_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (RV_C * (512 + 4) + 512) * 4));
+            attr3_set = true;
+        }
+    }
     if (ver == 2) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -222,7 +230,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         {
             Prof p(x, I_RESCORE);
             if (ver == 3)
-                hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_keys, streams, q_pad, x->rows, n,
+                hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), (size_t)(RV_C * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
                                    x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
                                    scan_eps_unit(x->dim) * x->row_norm_max);
             else
