@@ -275,18 +275,16 @@ static int launch_gemm_tn256p(hipStream_t st, const uint16_t* A, int lda, const 
 // workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 8 = four-phase with the deep prefetch (gemm_mfma256d.h, the default 256x256 mainloop), 3 = ring,
 // 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles, 7 = four-wave 256x256.  Auto picks the 160-row tiles when they put one workgroup on
 // more CUs than 256-row tiles would (VQ_AMD_GEMM160=0 disables that).
-static inline int gemm_use_deep() {           // $VQ_AMD_GEMM256 = 4phase | deep | 2phase: which 256x256 mainloop auto picks (A/B switch)
+static inline int gemm_use_deep() {           // $VQ_AMD_GEMM256=4phase: auto picks the second-generation mainloop (A/B switch)
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM256"); v = !e ? 1 : !strcmp(e, "4phase") ? 0 : !strcmp(e, "2phase") ? 2 : 1; }
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM256"); v = (e && !strcmp(e, "4phase")) ? 0 : 1; }
     return v;
 }
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256_best(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                                   int M, int N, int K, const Epi& epi) {
-    const int v = gemm_use_deep();
-    return v == 2 ? launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi)
-         : v == 1 ? launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi)
-                  : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    return gemm_use_deep() ? launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi)
+                           : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
 
 static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one launch per GEMM
@@ -327,8 +325,13 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
 #endif
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#ifdef VQ_GEMM_EXPERIMENTS
     if (force == 9) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#else
+    if (force == 9 || force == 10)
+        return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
+#endif
     if (force == 2) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     const bool want256 = force >= 2 || (force == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
 #ifdef VQ_GEMM_EXPERIMENTS

@@ -645,7 +645,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  const float* __restrict__ queries, int nq, int k,
                                  int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
                                  int32_t* __restrict__ flags, float eps_rows) {
-    __shared__ float kept_v[256 * RS_KEEP];
+    __shared__ __attribute__((aligned(16))) float kept_v[256 * RS_KEEP];
     __shared__ int kept_s[256 * RS_KEEP];
     __shared__ float sel_v[4 * RV_C];
     __shared__ int sel_s[4 * RV_C];
@@ -655,9 +655,9 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     __shared__ int cand_src[RV_C];
     __shared__ int cand_row[RV_POOL];
     __shared__ float cand_dist[RV_POOL];
-    __shared__ float bound_rest_s, floor_max_s, qnorm2_s;
+    __shared__ float bound_rest_s, floor_max_s, qnorm2_s, dk_s;
     __shared__ int resc_stream[RV_RESCAN_MAX];
-    __shared__ int resc_n, state, pool_n;
+    __shared__ int resc_n, state, pool_n, have_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -701,33 +701,40 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
 #pragma unroll
     for (int i = 0; i < RS_KEEP; ++i) { kept_v[tid * RS_KEEP + i] = kv[i]; kept_s[tid * RS_KEEP + i] = ksrc[i]; }
-    {   // |q|^2 and the largest dropped key: block reductions through `red`
+    {   // |q|^2 and the largest dropped key: wave shuffles, then four partials through `red`
         float s2 = 0.f;
         for (int i = tid; i < dim; i += 256) s2 += qv[i] * qv[i];
-        red[tid] = s2;
-        __syncthreads();
-        if (tid == 0) { float t = 0.f; for (int i = 0; i < 256; ++i) t += red[i]; qnorm2_s = t; }
-        __syncthreads();
-        red[tid] = dropped;
-        __syncthreads();
-        if (tid == 0) { float t = NEG; for (int i = 0; i < 256; ++i) t = fmaxf(t, red[i]); floor_max_s = t; resc_n = 0; state = 0; }
+        float dr = dropped;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); dr = fmaxf(dr, __shfl_xor(dr, o)); }
+        if (lane == 0) { red[wave] = s2; red[4 + wave] = dr; }
+        if (tid == 0) { resc_n = 0; state = 0; }
     }
     __syncthreads();
+    if (tid == 0) {
+        qnorm2_s = (red[0] + red[1]) + (red[2] + red[3]);
+        floor_max_s = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    }
 
     // ---- 2a. each wave: the best RV_C of its 64*RS_KEEP keys (rank = number of better keys, index breaks ties) ----
     {
         const int base = wave * 64 * RS_KEEP;
+        float vi[RS_KEEP]; int rank[RS_KEEP];
+#pragma unroll
+        for (int i = 0; i < RS_KEEP; ++i) { vi[i] = kept_v[base + lane * RS_KEEP + i]; rank[i] = 0; }
+        for (int j = 0; j < 64 * RS_KEEP; j += 4) {                       // 16-byte LDS reads, the same address in every lane
+            const float4 vj = *(const float4*)(kept_v + base + j);
+            const float v4[4] = {vj.x, vj.y, vj.z, vj.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < RS_KEEP; ++i)
+                    rank[i] += (v4[u] > vi[i]) || (v4[u] == vi[i] && j + u < lane * RS_KEEP + i);
+        }
 #pragma unroll
         for (int i = 0; i < RS_KEEP; ++i) {
-            const int me = lane * RS_KEEP + i;
-            const float vi = kept_v[base + me];
-            int rank = 0;
-            for (int j = 0; j < 64 * RS_KEEP; ++j) {
-                const float vj = kept_v[base + j];
-                rank += (vj > vi) || (vj == vi && j < me);
-            }
-            if (rank < RV_C) { sel_v[wave * RV_C + rank] = vi; sel_s[wave * RV_C + rank] = kept_s[base + me]; }
-            if (rank == RV_C) wave_floor[wave] = vi;
+            if (rank[i] < RV_C) { sel_v[wave * RV_C + rank[i]] = vi[i]; sel_s[wave * RV_C + rank[i]] = kept_s[base + lane * RS_KEEP + i]; }
+            if (rank[i] == RV_C) wave_floor[wave] = vi[i];
         }
     }
     __syncthreads();
@@ -777,20 +784,23 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
     __syncthreads();
 
-    // ---- 4. which bounds are still open? ----
+    // ---- 4. which bounds are still open?  k-th best exact distance by rank counting (one thread per candidate) ----
+    if (tid == 0) { dk_s = __builtin_inff(); have_s = 0; }
+    __syncthreads();
+    const int kk = k < RV_C ? k : RV_C;
+    if (tid < RV_C && cand_row[tid] >= 0) {
+        const uint64_t ki = dist_key(cand_dist[tid], (uint32_t)cand_row[tid]);
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < RV_C; ++j)
+            rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
+        if (rank == kk - 1) dk_s = cand_dist[tid];
+        atomicAdd(&have_s, 1);
+    }
+    __syncthreads();
     if (tid == 0) {
-        const int kk = k < RV_C ? k : RV_C;
-        float dk = __builtin_inff(); int have = 0;
-        for (int i = 0; i < RV_C; ++i) have += cand_row[i] >= 0;
-        if (have >= kk) {
-            for (int i = 0; i < RV_C; ++i) {
-                if (cand_row[i] < 0) continue;
-                int rank = 0;
-                for (int j = 0; j < RV_C; ++j)
-                    rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < dist_key(cand_dist[i], (uint32_t)cand_row[i]);
-                if (rank == kk - 1) dk = cand_dist[i];
-            }
-        }
+        const int have = have_s;
+        const float dk = have >= kk ? dk_s : __builtin_inff();
         const float sk = 1.0f - dk;
         const float eps = eps_rows * sqrtf(qnorm2_s);          // NaN for a non-finite query: every test fails -> exact fallback
         int st = 0, nres = 0;

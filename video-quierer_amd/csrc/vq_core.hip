@@ -155,15 +155,16 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
     auto once = [&]() {
 #ifdef VQ_GEMM_EXPERIMENTS
         if (kernel == 3) return launch_gemm_tn256_ring_diag<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, diag);
+        if (kernel == 9) return launch_gemm_tn256e<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        if (kernel == 10) return launch_gemm_tn256f<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 7) return launch_gemm_tn256w4<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 4) return launch_gemm_tn256p<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
 #else
-        if (kernel == 3 || kernel == 4 || kernel == 7)
+        if (kernel == 3 || kernel == 4 || kernel == 7 || kernel == 9 || kernel == 10)
             return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", kernel);
 #endif
         if (kernel == 8) return launch_gemm_tn256d<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
-        if (kernel == 9) return launch_gemm_tn256e<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
-        if (kernel == 10) return launch_gemm_tn256f<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         return launch_gemm_tn256_stamped<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N}, nullptr, diag);
