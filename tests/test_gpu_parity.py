@@ -631,7 +631,15 @@ def test_native_comm_world_of_one_over_rccl(gpu_lib):
     """vq_comm_* with a real RCCL communicator of one rank (all a one-GPU box can hold): the all-gather of rows is the
     identity, ragged counts included, and the sharded search returns the single-index answer with global ids."""
     from video_quierer_amd.comm import Comm
-    comm = Comm.single()
+    import socket
+    import torch.distributed as dist
+    # the bootstrap bench.py uses: rank 0's unique id travels through torch.distributed's store
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        comm = Comm.from_torch_distributed()
+    finally:
+        dist.destroy_process_group()
     assert comm.world == 1 and comm.rank == 0 and comm.rccl_version() > 0
     rng = np.random.default_rng(5)
     local = torch.from_numpy(rng.standard_normal((300, 512)).astype(np.float32)).cuda()
