@@ -179,6 +179,31 @@ struct EpiLnH16 {
     }
 };
 
+// Split-K partial planes: part[slice][m][n] = this K-slice's accumulators (gemm_mfma.h launch_gemm_tn_splitk)
+struct EpiSplitKPartialF32 {
+    float* part; int ld; int64_t plane; int slice = 0;
+    static constexpr bool kLoads = false, kSplitK = true;
+    __device__ __forceinline__ f32x4 bias_at(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4, f32x4) const {
+        *(f32x4*)(part + (size_t)slice * plane + (size_t)m * ld + n) = v;
+    }
+};
+
+// x[m*tokens][n] += bias[n] + sum over slices (in slice order) of part[s][m][n], m < m_valid     (last block's fc2, CLS rows)
+__global__ __launch_bounds__(256)
+void splitk_reduce_residual_cls_kernel(const float* __restrict__ part, int64_t plane, int splits, float* __restrict__ x,
+                                       const float* __restrict__ bias, int hidden, int tokens, int m_valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one float4 of one CLS row
+    const int per_row = hidden >> 2;
+    if (i >= m_valid * per_row) return;
+    const int m = i / per_row, n = (i - m * per_row) * 4;
+    f32x4 acc = ld4(bias + n);
+    for (int s = 0; s < splits; ++s) acc = acc + ld4(part + (size_t)s * plane + (size_t)m * hidden + n);
+    float* xr = x + (size_t)m * tokens * hidden + n;
+    *(f32x4*)xr = ld4(xr) + acc;
+}
+
 // Patch-embedding GEMM: GEMM row m = (image b, patch p) -> token row b*T + 1 + p;
 // x = acc + folded_bias + position_embedding[1+p]          (E3)
 struct EpiPatchEmbedF32 {

@@ -95,6 +95,8 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
 //              second per-column constant aux_at(n); its store is store_ln(m, n, acc, bias, aux, stat)
 template <class E, class = void> struct epi_row_stats : std::false_type {};
 template <class E> struct epi_row_stats<E, std::void_t<decltype(E::kRowStats)>> : std::bool_constant<E::kRowStats> {};
+template <class E, class = void> struct epi_split_k : std::false_type {};
+template <class E> struct epi_split_k<E, std::void_t<decltype(E::kSplitK)>> : std::bool_constant<E::kSplitK> {};
 template <class E, class = void> struct epi_row_in : std::false_type {};
 template <class E> struct epi_row_in<E, std::void_t<decltype(E::kRowIn)>> : std::bool_constant<E::kRowIn> {};
 
@@ -186,7 +188,7 @@ template <bool IS_F16, class Epi>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                     const uint16_t* __restrict__ W, int ldw,
-                    int K, int tiles_n, Epi epi, int m_base) {
+                    int K, int tiles_n, Epi epi, int m_base, int tiles = 0 /* > 0: split-K — workgroup wg covers K-slice wg / tiles of tile wg % tiles (K = slice length) */) {
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES + GEMM_BM * 8];     // + (mean, rstd) per tile row (kRowIn)
@@ -196,7 +198,9 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int kslice = 0;
+    if (tiles > 0) { kslice = wg / tiles; wg -= kslice * tiles; A += (size_t)kslice * K; W += (size_t)kslice * K; }
     const int m0 = m_base + (wg / tiles_n) * GEMM_BM;        // m_base: first row of the strip this launch covers
     const int n0 = (wg % tiles_n) * GEMM_BN;
 
@@ -244,7 +248,8 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
 
     const int nk = K / GEMM_BK;
     stage(0, 0);
-    const Epi epi_wg = epi_bind_rowstats<GEMM_BM>(epi, (float2*)(smem + GEMM_LDS_BYTES), m0, tid, GEMM_THREADS);
+    Epi epi_wg = epi_bind_rowstats<GEMM_BM>(epi, (float2*)(smem + GEMM_LDS_BYTES), m0, tid, GEMM_THREADS);
+    if constexpr (epi_split_k<Epi>::value) epi_wg.slice = kslice;
     __syncthreads();          // emits vmcnt(0): the DMA has landed for every wave
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -271,6 +276,24 @@ void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
 
     // ---- epilogue (the last __syncthreads() retired every fragment read: LDS is free) ----
     wave_epilogue<4>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wm * 64, n0 + wn * 64, lane, epi_wg);
+}
+
+// Split-K form for GEMMs with few output tiles and a long K (the CLS-only last block: 12 tiles x K = 3072): `splits`
+// workgroups per tile, each over K / splits, results to the functor's per-slice partial planes (kSplitK functors);
+// a reduce kernel (encoder_kernels.h) sums the planes in slice order, so the result does not depend on timing.
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn_splitk(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                                 int M, int N, int K, int splits, const Epi& epi) {
+    static_assert(epi_split_k<Epi>::value, "split-K needs a functor with per-slice outputs");
+    VQ_CHECK(M > 0 && M % GEMM_BM == 0 && N % GEMM_BN == 0 && splits > 0 && K % (splits * GEMM_BK) == 0,
+             "gemm_tn_splitk: shape M=%d N=%d K=%d / %d slices is not tile-aligned", M, N, K, splits);
+    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn_splitk: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    const int tiles_m = M / GEMM_BM, tiles_n = N / GEMM_BN;
+    hipLaunchKernelGGL((gemm_tn_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n * splits), dim3(GEMM_THREADS), 0, st,
+                       A, lda, W, ldw, K / splits, tiles_n, epi, 0, tiles_m * tiles_n);
+    VQ_HIP(hipGetLastError());
+    return 0;
 }
 
 template <bool IS_F16, class Epi>

@@ -341,12 +341,25 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                     });
                 }));
             }
-            {
+            {   // 2 x 6 output tiles over K = mlp: split-K so that ~100 workgroups share the long K loop; partial planes
+                // live in the (now free) q|k|v buffer, summed in slice order by the reduce kernel
                 Prof p(e, C_GEMM_FC2);
-                VQ_TRY(by_f16(f2, [&](auto F) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp,
-                                                       EpiBiasResidualClsF32{e->x, H, T, L.b_fc2, n}, e->gemm_force);
-                }));
+                const int splits = (c.mlp % (8 * GEMM_BK) == 0 && (size_t)8 * crows * H * 2 <= (size_t)e->rows_pad * 3 * H) ? 8 : 0;
+                if (splits && crows % GEMM_BM == 0 && e->gemm_force != 2 && e->gemm_force != 8) {
+                    float* part = (float*)e->qkv;
+                    const int64_t plane = (int64_t)crows * H;
+                    VQ_TRY(by_f16(f2, [&](auto F) {
+                        return launch_gemm_tn_splitk<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp, splits,
+                                                                EpiSplitKPartialF32{part, H, plane});
+                    }));
+                    hipLaunchKernelGGL(splitk_reduce_residual_cls_kernel, dim3(cdiv((int64_t)n * (H / 4), 256)), dim3(256), 0, st, part, plane,
+                                       splits, e->x, L.b_fc2, H, T, n);
+                } else {
+                    VQ_TRY(by_f16(f2, [&](auto F) {
+                        return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, crows, H, c.mlp,
+                                                           EpiBiasResidualClsF32{e->x, H, T, L.b_fc2, n}, e->gemm_force);
+                    }));
+                }
             }
             continue;
         }
