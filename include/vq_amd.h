@@ -181,6 +181,9 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
 /* Diagnostic: average launch time of the deep-prefetch 256x256 mainloop on random data and the clock (GHz) the chip
  * holds inside its K loop (d s_memtime / d s_memrealtime, median over workgroups). */
 int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz_median);
+/* Diagnostic: s_memtime stamps of workgroup 0 of that mainloop, four per phase (phase start, before the mid barrier,
+ * before the MFMAs, after them): stamps[8 waves][512]. */
+int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long* stamps);
 
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;

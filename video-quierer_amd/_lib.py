@@ -92,6 +92,7 @@ SIGNATURES = {
     "vq_resampler_device_output": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "vq_clip_processor_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vq_debug_gemm_clock": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "vq_debug_gemm_stamps_deep": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "vq_comm_unique_id": (c_int, [c_void_p, c_int]),
     "vq_comm_init": (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "vq_comm_destroy": (c_int, [c_void_p]),

@@ -40,9 +40,10 @@
 
 namespace vq {
 
+constexpr int G2D_STAMPS = 512;                    // per wave, CLOCK == 2 diagnostic builds
 constexpr int G2_ROWSTAT_BYTES = G2_BM * 8;      // (mean, rstd) per tile row behind the two K-tile buffers (kRowIn epilogues)
 
-template <bool IS_F16, class Epi, bool CLOCK = false>
+template <bool IS_F16, class Epi, int CLOCK = 0 /* diagnostic builds: 1 = clock around the K loop, 2 = s_memtime stamps per phase */>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
                         const uint16_t* __restrict__ W, int ldw,
@@ -144,38 +145,64 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         asm volatile("" ::: "memory");
     };
 #define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+    // CLOCK == 2: four s_memtime stamps per phase (start, before the mid barrier, before the MFMAs, after them) kept in
+    // the LDS behind the two K-tile buffers (the launch asks for 160 KiB then)
+    unsigned long long* stamp_lds = (unsigned long long*)(smem + G2_LDS_BYTES);
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if constexpr (CLOCK == 2) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (stamp_i < G2D_STAMPS) { if (lane == 0) stamp_lds[wave * G2D_STAMPS + stamp_i] = t; ++stamp_i; }
+        }
+    };
 
     auto tile = [&](int kt, int bufi) {
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
         // phase 1: quadrant (0,0)
+        stamp();
         load_a(buf, 0); load_w(buf, 0);
         if (next) { stage_w(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }       // newer than W1(t): A1(t) A0(t+1) W0(t+1) W1(t+1)
         else      { VQ_VMCNT(2); }                                     //                   A1(t)
+        stamp();
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
         mfma_quadrant(0, 0);
+        stamp();
         barrier();
         // phase 2: quadrant (0,1)
+        stamp();
         load_w(buf, 1);
         if (next) { stage_a(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }       // newer than A1(t): A0(t+1) W0(t+1) W1(t+1) A1(t+1)
         else      { VQ_VMCNT(0); }
+        stamp();
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
         mfma_quadrant(0, 1);
+        stamp();
         barrier();
         // phase 3: quadrant (1,1)
+        stamp();
         load_a(buf, 1);
         if (next2) stage_a(bufi, 0, kt + 2);
+        stamp();
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
         mfma_quadrant(1, 1);
+        stamp();
         barrier();
         // phase 4: quadrant (1,0): no fragment reads (A1 and W0 are in registers)
+        stamp();
         if (next2)     { stage_w(bufi, 0, kt + 2); VQ_VMCNT(8); }      // newer than W0(t+1): W1(t+1) A1(t+1) A0(t+2) W0(t+2)
         else if (next) { VQ_VMCNT(4); }                                //                     W1(t+1) A1(t+1)
+        stamp();
         barrier();
+        stamp();
         mfma_quadrant(1, 0);
+        stamp();
         barrier();
     };
 
@@ -189,7 +216,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     barrier();
 
     unsigned long long c0 = 0, r0 = 0;
-    if constexpr (CLOCK) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (CLOCK == 1) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; kt += 2) {
@@ -200,9 +227,14 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     barrier();                            // both groups past their last fragment reads before LDS is reused
 #undef VQ_VMCNT
 
-    if constexpr (CLOCK) {
+    if constexpr (CLOCK == 1) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) { clock_out[blockIdx.x * 2] = c1 - c0; clock_out[blockIdx.x * 2 + 1] = r1 - r0; }
+    }
+    if constexpr (CLOCK == 2) {           // stamps of workgroup 0: LDS -> clock_out[wave][G2D_STAMPS]
+        if (blockIdx.x == 0)
+            for (int i = lane; i < G2D_STAMPS; i += 64) clock_out[wave * G2D_STAMPS + i] = stamp_lds[wave * G2D_STAMPS + i];
+        __syncthreads();
     }
 
     wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi_wg);

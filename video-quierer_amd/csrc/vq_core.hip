@@ -198,11 +198,11 @@ int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz
     VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
     VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     typedef EpiStoreF32 E;
-    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0)); VQ_HIP(hipEventCreate(&e1));
     auto once = [&]() {
-        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, true>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr,
+        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 1>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr,
                            dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
     };
     for (int i = 0; i < 3; ++i) once();
@@ -220,6 +220,32 @@ int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz
     std::sort(ghz.begin(), ghz.end());
     *ghz_median = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dS);
+    return 0;
+}
+
+// Diagnostic: per-phase s_memtime stamps of workgroup 0 of the deep-prefetch mainloop (four per phase: phase start, before
+// the mid barrier, before the MFMAs, after the MFMAs), random operands, after `reps` back-to-back launches.
+int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long* stamps /*[8][512]*/) {
+    VQ_TRY(require_init());
+    VQ_CHECK(stamps && reps > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0, "vq_debug_gemm_stamps_deep: bad argument");
+    uint16_t *dA = nullptr, *dW = nullptr; float* dC = nullptr; unsigned long long* dS = nullptr;
+    VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2)); VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4));
+    VQ_HIP(hipMalloc(&dS, (size_t)8 * G2D_STAMPS * 8));
+    std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t r = 999;
+    for (auto& v : a16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    for (auto& v : w16) { r = r * 1664525u + 1013904223u; v = f32_to_bf16_rne(((int)(r >> 8) % 2001 - 1000) * 1e-3f); }
+    VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    typedef EpiStoreF32 E;
+    const int lds = G2_LDS_BYTES + 8 * G2D_STAMPS * 8;
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 2>), dim3((M / 256) * (N / 256)), dim3(G2_THREADS), lds, nullptr,
+                           dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
+    VQ_HIP(hipDeviceSynchronize());
+    VQ_HIP(hipMemcpy(stamps, dS, (size_t)8 * G2D_STAMPS * 8, hipMemcpyDeviceToHost));
     (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dS);
     return 0;
 }
