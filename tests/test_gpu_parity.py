@@ -626,6 +626,42 @@ def test_merge_of_two_row_shards_on_one_device_is_the_single_index_answer(gpu_li
         assert list(out_ids[0, :2].cpu().numpy()) == [3, 700]
 
 
+def test_sharded_search_at_the_scale_config_geometry(gpu_lib):
+    """configs[4]'s index geometry on one device at reduced size: 768-d rows (ViT-L/14 embeddings), two row shards large
+    enough for the fp16 MFMA scan (>= 16,384 rows each), a 300-query batch and a single query, merged by the library's
+    merge kernel — ids and distances bit-identical to the exact oracle over the whole matrix."""
+    from video_quierer_amd.comm import merge_topk_device
+    rng = np.random.default_rng(768)
+    n, d, k = 34000, 768, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[20000] = rows[5]                                 # a tie across the shard boundary
+    qs = rng.standard_normal((300, d)).astype(np.float32)
+    qs[0] = rows[5]
+    shards, stored = [], []
+    for lo, hi in ((0, 17000), (17000, n)):
+        idx = _mk_index(rows[lo:hi])
+        stored.append(idx._export())
+        shards.append((lo, idx))
+    uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    oid, od = knn_oracle.topk(np.concatenate(stored), uq, k)
+    for nq in (300, 1):
+        q_t = torch.from_numpy(uq[:nq]).cuda()
+        parts = []
+        for lo, idx in shards:
+            ids, dd = _device_search(idx, q_t, k)
+            parts.append((torch.where(ids >= 0, ids + lo, ids), dd))
+        all_ids = torch.stack([p[0] for p in parts]).contiguous()
+        all_d = torch.stack([p[1] for p in parts]).contiguous()
+        out_ids = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        out_d = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        merge_topk_device(all_ids.data_ptr(), all_d.data_ptr(), 2, nq, k, out_ids.data_ptr(), out_d.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out_ids.cpu().numpy(), oid[:nq]) and np.array_equal(out_d.cpu().numpy(), od[:nq])
+    assert list(oid[0, :2]) == [5, 20000]
+    for _, idx in shards:
+        idx.close()
+
+
 @pytest.mark.timeout(180)
 def test_native_comm_world_of_one_over_rccl(gpu_lib):
     """vq_comm_* with a real RCCL communicator of one rank (all a one-GPU box can hold): the all-gather of rows is the
