@@ -43,7 +43,8 @@ namespace vq {
 constexpr int G2D_STAMPS = 512;                    // per wave, CLOCK == 2 diagnostic builds
 constexpr int G2_ROWSTAT_BYTES = G2_BM * 8;      // (mean, rstd) per tile row behind the two K-tile buffers (kRowIn epilogues)
 
-template <bool IS_F16, class Epi, int CLOCK = 0 /* diagnostic builds: 1 = clock around the K loop, 2 = s_memtime stamps per phase */>
+template <bool IS_F16, class Epi, int CLOCK = 0 /* diagnostic builds: 1 = clock around the K loop, 2 = s_memtime stamps per phase */,
+          bool BUF = false /* LDS-DMA as buffer_load ... lds (descriptor + 32-bit lane offset + scalar K offset) instead of global_load_lds */>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
                         const uint16_t* __restrict__ W, int ldw,
@@ -84,18 +85,40 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
             a_dst[h][i] = arow0 * 128;                       // A region = first 32 KiB of a buffer (two 16-KiB halves)
             w_dst[h][i] = 2 * G2_HALF + wrow0 * 128;         // W region = second 32 KiB
         }
+    // BUF: one descriptor per operand (base = the tile's first row: workgroup-uniform), the lane's byte offset inside
+    // the tile in a VGPR, the K offset in an SGPR — no 64-bit address arithmetic per piece
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, 0x7fffffff, 0x00020000);
+    int a_voff[2][2], w_voff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_voff[h][i] = (int)((a_src[h][i] - (A + (size_t)m0 * lda)) * 2);
+            w_voff[h][i] = (int)((w_src[h][i] - (W + (size_t)n0 * ldw)) * 2);
+        }
 
     auto stage_a = [&](int buf, int hm, int kt) {
         char* base = smem + buf * G2_BUF;
         const int koff = kt * G2_BK;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
+        if constexpr (BUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][0]), 16, a_voff[hm][0], koff * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][1]), 16, a_voff[hm][1], koff * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
+        }
     };
     auto stage_w = [&](int buf, int hn, int kt) {
         char* base = smem + buf * G2_BUF;
         const int koff = kt * G2_BK;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
+        if constexpr (BUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][0]), 16, w_voff[hn][0], koff * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][1]), 16, w_voff[hn][1], koff * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
+        }
     };
 
     // ---- fragment read offsets (identical to gemm_tn256_kernel) ----
@@ -406,7 +429,7 @@ static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const 
     }
 }
 
-template <bool IS_F16, class Epi>
+template <bool IS_F16, class Epi, bool BUF = false>
 static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                               int M, int N, int K, const Epi& epi) {
     VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
@@ -415,12 +438,12 @@ static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const 
              "gemm_tn256d: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
     static bool attr_set = false;       // per instantiation; one device per process (vq_init)
     if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<IS_F16, Epi>,
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<IS_F16, Epi, 0, BUF>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + G2_ROWSTAT_BYTES));
         attr_set = true;
     }
     const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
-    hipLaunchKernelGGL((gemm_tn256d_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
+    hipLaunchKernelGGL((gemm_tn256d_kernel<IS_F16, Epi, 0, BUF>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
                        G2_LDS_BYTES + (epi_row_in<Epi>::value ? G2_ROWSTAT_BYTES : 0), st,
                        A, lda, W, ldw, K, tiles_n, epi, gemm_order2d(), (unsigned long long*)nullptr);
     VQ_HIP(hipGetLastError());

@@ -325,6 +325,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
 #endif
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, true>(st, A, lda, W, ldw, M, N, K, epi);
 #ifdef VQ_GEMM_EXPERIMENTS
     if (force == 9) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);

@@ -164,6 +164,7 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
             return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", kernel);
 #endif
         if (kernel == 8) return launch_gemm_tn256d<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        if (kernel == 11) return launch_gemm_tn256d<false, EpiStoreF32, true>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
 
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
