@@ -429,7 +429,7 @@ static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const 
     }
 }
 
-template <bool IS_F16, class Epi, bool BUF = false>
+template <bool IS_F16, class Epi, bool BUF = true /* false: global_load_lds staging (A/B: 1.5-3.5 % slower, 18 more VGPRs) */>
 static int launch_gemm_tn256d(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                               int M, int N, int K, const Epi& epi) {
     VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,

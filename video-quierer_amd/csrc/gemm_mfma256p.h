@@ -272,7 +272,7 @@ static int launch_gemm_tn256p(hipStream_t st, const uint16_t* A, int lda, const 
 }
 
 // Dispatch: the phased 256x256 kernel when the problem tiles by it and yields enough
-// workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 8 = four-phase with the deep prefetch (gemm_mfma256d.h, the default 256x256 mainloop), 3 = ring,
+// workgroups to occupy the chip, else the 128x128 kernel.  force: 1 = 128x128, 2 = four-phase, 8 = four-phase with the deep prefetch and buffer_load..lds staging (gemm_mfma256d.h, the default 256x256 mainloop), 11 = the same with global_load_lds staging, 3 = ring,
 // 4 = persistent four-phase, 5 = 160x256 ring, 6 = auto without the 160-row tiles, 7 = four-wave 256x256.  Auto picks the 160-row tiles when they put one workgroup on
 // more CUs than 256-row tiles would (VQ_AMD_GEMM160=0 disables that).
 static inline int gemm_use_deep() {           // $VQ_AMD_GEMM256=4phase: auto picks the second-generation mainloop (A/B switch)
@@ -325,7 +325,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
 #endif
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
-    if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, true>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, false>(st, A, lda, W, ldw, M, N, K, epi);
 #ifdef VQ_GEMM_EXPERIMENTS
     if (force == 9) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);

@@ -164,7 +164,7 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
             return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", kernel);
 #endif
         if (kernel == 8) return launch_gemm_tn256d<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
-        if (kernel == 11) return launch_gemm_tn256d<false, EpiStoreF32, true>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
+        if (kernel == 11) return launch_gemm_tn256d<false, EpiStoreF32, false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
 
         if (kernel == 1) return launch_gemm_tn<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
         if (kernel == 5) return launch_gemm_tn160_ring<false>(nullptr, dA, K, dW, K, M, N, K, EpiStoreF32{dC, N});
@@ -199,11 +199,11 @@ int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz
     VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
     VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     typedef EpiStoreF32 E;
-    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0)); VQ_HIP(hipEventCreate(&e1));
     auto once = [&]() {
-        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 1>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr,
+        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 1, true>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr,
                            dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
     };
     for (int i = 0; i < 3; ++i) once();
@@ -241,9 +241,9 @@ int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long*
     VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     typedef EpiStoreF32 E;
     const int lds = G2_LDS_BYTES + 8 * G2D_STAMPS * 8;
-    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<false, E, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 2>), dim3((M / 256) * (N / 256)), dim3(G2_THREADS), lds, nullptr,
+        hipLaunchKernelGGL((gemm_tn256d_kernel<false, E, 2, true>), dim3((M / 256) * (N / 256)), dim3(G2_THREADS), lds, nullptr,
                            dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
     VQ_HIP(hipDeviceSynchronize());
     VQ_HIP(hipMemcpy(stamps, dS, (size_t)8 * G2D_STAMPS * 8, hipMemcpyDeviceToHost));
