@@ -211,8 +211,8 @@ int vq_index_clear(vq_index* idx);
  * fp16 path's exactness bound scales with each query's own norm, so un-normalised queries stay exact.  ids/dist are [nq][k]; unused slots
  * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 32), 1 exact
  * fp32-master scan, 2 fp16 MFMA scan + exact re-score with proof (unproven queries are redone by the
- * exact scan).  The fp16 path reads its per-query outcome flags back, so vq_index_search_device returns
- * with the stream drained in that mode; the exact mode is fully asynchronous. */
+ * exact scan, on the device: nothing is read back).  vq_index_search_device is asynchronous on the index's
+ * stream in every mode; vq_index_last_search_stats waits for that stream. */
 int vq_index_search(vq_index* idx, const float* queries, int nq, int k, int mode,
                     int32_t* ids, float* dist);
 int vq_index_search_device(vq_index* idx, const void* d_queries_f32, int nq, int k, int mode,

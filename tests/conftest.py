@@ -39,6 +39,33 @@ def b32_weights():
     return seeded_weights(VIT_B_32, WEIGHT_SEED)
 
 
+def outlier_weights(seed=WEIGHT_SEED):
+    """Seeded ViT-B/32 weights reshaped towards what trained CLIP checkpoints look like (parity on
+    N(0, 1/fan_in) weights alone says nothing about outlier channels): three "massive activation" channels that two
+    MLP blocks write into the residual stream (|x| of 25-60 beside O(1) neighbours), LayerNorm gains spread over a
+    log-normal with the hot channels damped in the later blocks, a large class token, a pre-LayerNorm that amplifies
+    the hot channels, and heavy-tailed linear weights (0.5 % of the entries six times larger)."""
+    from video_quierer_amd.weights import VIT_B_32, seeded_weights
+    W = {k: v.copy() for k, v in seeded_weights(VIT_B_32, seed).items()}
+    rng = np.random.default_rng([seed, 77])
+    hot = np.array([7, 133, 520])
+    for name, w in W.items():
+        if name.endswith(("q_proj.weight", "k_proj.weight", "v_proj.weight", "out_proj.weight", "fc1.weight", "fc2.weight")):
+            mask = rng.random(w.shape) < 0.005
+            w[mask] *= 6.0
+        elif name.endswith(("layer_norm1.weight", "layer_norm2.weight")):
+            w *= np.exp(0.5 * rng.standard_normal(w.shape)).astype(np.float32)
+    for l, amp in ((2, (40.0, -60.0, 25.0)), (5, (-15.0, 30.0, 20.0))):
+        W[f"vision_model.encoder.layers.{l}.mlp.fc2.bias"][hot] += np.array(amp, np.float32)
+        W[f"vision_model.encoder.layers.{l}.mlp.fc2.weight"][hot, :] *= 4.0
+    for l in range(3, 12):
+        for ln in ("layer_norm1", "layer_norm2"):
+            W[f"vision_model.encoder.layers.{l}.{ln}.weight"][hot] *= 0.1
+    W["vision_model.pre_layrnorm.weight"][hot] *= 6.0
+    W["vision_model.embeddings.class_embedding"] *= 5.0
+    return W
+
+
 @pytest.fixture(scope="session")
 def gpu_lib():
     """Binds the GPU once; GPU tests fail (not skip) if the native library cannot run."""

@@ -117,6 +117,31 @@ def test_encoder_matches_golden_embeddings(encoder, golden_encoder):
     assert diff.max() <= COS_TOL
 
 
+def test_encoder_parity_with_outlier_channels(gpu_lib):
+    """Weights with the outlier structure of trained checkpoints (conftest.outlier_weights: massive-activation channels
+    in the residual stream, log-normal LayerNorm gains, heavy-tailed linear weights): the default operand types still
+    hold the north star's 1e-3 on every score, against the fp32 oracle run here on the same frames."""
+    from conftest import outlier_weights
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    W = outlier_weights()
+    frames = synth_frames(32, seed=4242)
+    ref = clip_vit_oracle.encode_frames(frames, W, batch_size=16)
+    hid = _oracle_hidden(frames[:4], W, 3)
+    ratio = np.abs(hid).max() / np.median(np.abs(hid))
+    assert ratio > 30, f"the fixture lost its outliers: max/median |x| = {ratio}"       # the residual stream really has them
+    rows = knn_oracle.normalize_rows(np.random.default_rng(INDEX_SEED).standard_normal((1000, 512)).astype(np.float32))
+    for dt in ("mixed", "fp16"):
+        enc = VitEncoder(VIT_B_32, W, max_batch=32, compute_dtype=dt)
+        emb = enc.encode(frames)
+        enc.close()
+        cos = np.sum(emb * ref, axis=1)
+        diff = np.abs(emb @ rows.T - ref @ rows.T)
+        print(f"outlier weights ({dt}): residual max/median {ratio:.0f}, min cos {cos.min():.7f}, score diff max {diff.max():.2e}")
+        assert np.all(np.isfinite(emb)) and cos.min() >= 1.0 - COS_TOL
+        assert diff.max() <= COS_TOL
+
+
 def test_encoder_fp16_operands_are_8x_closer(gpu_lib, b32_weights, golden_encoder):
     """compute_dtype="fp16": same kernels instantiated for fp16 MFMA operands (what ViT-L/14@336 is specified
     with); the embedding error drops from ~5e-3 (bf16) to <1e-3 in L2 and every pairwise score is within 3e-4."""
@@ -494,6 +519,14 @@ def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
     st = _scan_vs_oracle(same, same[:3] + 0, 5)
     print("fp16 scan, all-identical rows:", st)
     assert st["exact_fallback"] == 3
+    # the device-side fallback with many flagged queries: several groups of 8 per row split, both slot lanes, a ragged
+    # last group, a ragged last row split, k = 32 (full lists) - every query through the exact fallback, bit-exact
+    same = np.tile(rng.standard_normal((1, 128)).astype(np.float32), (18001, 1))
+    same[::7] *= 1.0 + 1e-7 * rng.standard_normal((len(same[::7]), 1)).astype(np.float32)      # a few distinct distances among the ties
+    st = _scan_vs_oracle(same, same[:301] + 0, 32)
+    assert st["exact_fallback"] == 301
+    st = _scan_vs_oracle(same[:16385], same[:70] + 0, 3)      # batch path (> 64 queries), 9 row splits of 2048 with a 1-row tail
+    assert st["exact_fallback"] == 70
 
 
 # ------------------------------------------------------------------ live system's brute-force index ("next" #2)

@@ -855,25 +855,4 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
 }
 
-// Copies the exact-scan results of the flagged queries over the fast-path results.
-__global__ void patch_results_kernel(const int32_t* __restrict__ slot_query, int nslots, int k,
-                                     const int32_t* __restrict__ ex_ids, const float* __restrict__ ex_dist,
-                                     int32_t* __restrict__ ids, float* __restrict__ dist) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nslots * k) return;
-    const int s = i / k, j = i - s * k;
-    const int q = slot_query[s];
-    ids[(size_t)q * k + j] = ex_ids[i];
-    dist[(size_t)q * k + j] = ex_dist[i];
-}
-
-// Gathers the flagged queries' vectors into a compact array.
-__global__ void gather_queries_kernel(const float* __restrict__ queries, const int32_t* __restrict__ slot_query,
-                                      int nslots, int dim, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)nslots * dim) return;
-    const int s = (int)(i / dim);
-    out[i] = queries[(size_t)slot_query[s] * dim + (i - (int64_t)s * dim)];
-}
-
 }  // namespace vq

@@ -5,6 +5,7 @@
 #include "vq_common.h"
 #include "knn_kernels.h"
 #include "knn_scan_f16.h"
+#include "knn_fallback.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -36,11 +37,12 @@ struct vq_index {
     uint16_t* d_q16 = nullptr; int64_t q16_cap = 0;
     uint32_t* d_keys = nullptr; int64_t keys_cap = 0;
     int32_t* d_flags = nullptr; int64_t flags_cap = 0;
-    int32_t* h_flags = nullptr; int64_t hflags_cap = 0;       // pinned
+    // device-side fallback (knn_fallback.h): flagged query numbers, counters {flagged, proven, rescanned, fallback},
+    // per-split top-k lists; the counters travel to pinned memory behind the search, read by last_search_stats
     int32_t* d_slots = nullptr; int64_t slots_cap = 0;
-    float* d_fbq = nullptr; int64_t fbq_cap = 0;              // gathered fallback queries
-    int32_t* d_fb_ids = nullptr; int64_t fbi_cap = 0;
-    float* d_fb_dist = nullptr; int64_t fbd_cap = 0;
+    int32_t* d_counters = nullptr; int32_t* h_counters = nullptr;
+    uint64_t* d_fb_partial = nullptr; int64_t fbp_cap = 0;
+    bool stats_pending = false;    // the last search's counters are still on their way to h_counters
     int64_t stats[3] = {0, 0, 0};
     // |row|^2 range of rows added without normalisation (device: min/max fp32 bits); read back lazily by the first
     // search after such an add.  near_unit = the fp16 scan's error bound applies (knn_scan_f16.h scan_eps_unit).
@@ -155,6 +157,7 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
     }
     VQ_HIP(hipGetLastError());
     x->stats[0] = 0; x->stats[1] = 0; x->stats[2] = nq;
+    x->stats_pending = false;
     return 0;
 }
 
@@ -175,12 +178,16 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     VQ_TRY(reserve_buf(x->d_q16, x->q16_cap, q_chunk * x->dim));
     VQ_TRY(reserve_buf(x->d_keys, x->keys_cap, streams * q_chunk * 2));
     VQ_TRY(reserve_buf(x->d_flags, x->flags_cap, round_up(nq, QT)));
-    if (x->hflags_cap < nq) {
-        if (x->h_flags) (void)hipHostFree(x->h_flags);
-        x->h_flags = nullptr; x->hflags_cap = 0;
-        VQ_HIP(hipHostMalloc((void**)&x->h_flags, (size_t)round_up(nq, 1024) * 4));
-        x->hflags_cap = round_up(nq, 1024);
+    VQ_TRY(reserve_buf(x->d_slots, x->slots_cap, round_up(nq, 1024)));
+    if (!x->d_counters) {
+        VQ_HIP(hipMalloc((void**)&x->d_counters, FB_NCOUNTERS * 4));
+        VQ_HIP(hipHostMalloc((void**)&x->h_counters, FB_NCOUNTERS * 4));
     }
+    // row splits of the fallback scan and how many flagged queries one round of it may take (scratch <= 64 MiB)
+    const int fb_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_SPLIT_ROWS)));
+    const int64_t fb_rows = round_up(cdiv(n, fb_splits), FB_TILE);
+    const int64_t fb_cap = std::max<int64_t>(FB_QG, std::min<int64_t>(round_up(nq, FB_QG), ((int64_t)64 << 20) / ((int64_t)fb_splits * k * 8) / FB_QG * FB_QG));
+    VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, fb_cap * fb_splits * k));
     const int ranges = (int)(n_pad / RANGE);
     if (ver == 3) {
         static bool attr3_set = false;
@@ -240,32 +247,23 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
     }
     VQ_HIP(hipGetLastError());
-    // outcome flags -> host; queries the proof could not close are redone by the exact scan
-    VQ_HIP(hipMemcpyAsync(x->h_flags, x->d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, x->stream));
-    VQ_HIP(hipStreamSynchronize(x->stream));
-    std::vector<int32_t> slots;
-    int64_t st[3] = {0, 0, 0};
-    for (int i = 0; i < nq; ++i) {
-        const int f = x->h_flags[i];
-        st[f < 0 || f > 2 ? 2 : f]++;
-        if (f != 0 && f != 1) slots.push_back(i);
+    // Queries the proof could not close are redone by the exact scan, on the device: the flags are compacted into a
+    // list and the fallback kernels size themselves from its length (all of them leave at once when it is empty), so
+    // nothing here waits for the stream.  Rounds beyond the first exist only when more queries could be flagged than
+    // one round's scratch holds.
+    hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
+    {
+        Prof p(x, I_EXACT_DIST);
+        for (int64_t base = 0; base < nq; base += fb_cap) {
+            hipLaunchKernelGGL(exact_fallback_kernel, dim3(fb_splits, FB_SLOT_LANES), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
+                               d_queries, x->d_slots, x->d_counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial);
+            hipLaunchKernelGGL(fallback_merge_kernel, dim3(64), dim3(256), 0, x->stream, x->d_fb_partial, fb_splits, k, x->d_slots,
+                               x->d_counters, (int)base, (int)fb_cap, d_ids, d_dist_out);
+        }
     }
-    if (!slots.empty()) {
-        const int ns = (int)slots.size();
-        VQ_TRY(reserve_buf(x->d_slots, x->slots_cap, ns));
-        VQ_TRY(reserve_buf(x->d_fbq, x->fbq_cap, (int64_t)ns * x->dim));
-        VQ_TRY(reserve_buf(x->d_fb_ids, x->fbi_cap, (int64_t)ns * k));
-        VQ_TRY(reserve_buf(x->d_fb_dist, x->fbd_cap, (int64_t)ns * k));
-        VQ_HIP(hipMemcpyAsync(x->d_slots, slots.data(), (size_t)ns * 4, hipMemcpyHostToDevice, x->stream));
-        hipLaunchKernelGGL(gather_queries_kernel, dim3(cdiv((int64_t)ns * x->dim, 256)), dim3(256), 0, x->stream, d_queries,
-                           x->d_slots, ns, x->dim, x->d_fbq);
-        VQ_TRY(search_exact(x, x->d_fbq, ns, k, x->d_fb_ids, x->d_fb_dist));
-        hipLaunchKernelGGL(patch_results_kernel, dim3(cdiv((int64_t)ns * k, 256)), dim3(256), 0, x->stream, x->d_slots, ns, k,
-                           x->d_fb_ids, x->d_fb_dist, d_ids, d_dist_out);
-        VQ_HIP(hipGetLastError());
-        VQ_HIP(hipStreamSynchronize(x->stream));       // `slots` (host) must outlive the copy
-    }
-    x->stats[0] = st[0]; x->stats[1] = st[1]; x->stats[2] = st[2];
+    VQ_HIP(hipGetLastError());
+    VQ_HIP(hipMemcpyAsync(x->h_counters, x->d_counters, FB_NCOUNTERS * 4, hipMemcpyDeviceToHost, x->stream));
+    x->stats_pending = true;
     return 0;
 }
 
@@ -334,8 +332,8 @@ int vq_index_destroy(vq_index* x) {
     (void)hipFree(x->rows); (void)hipFree(x->rows16); (void)hipFree(x->d_q); (void)hipFree(x->d_dist);
     (void)hipFree(x->d_ids); (void)hipFree(x->d_out); (void)hipFree(x->d_partial);
     (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
-    (void)hipFree(x->d_fbq); (void)hipFree(x->d_fb_ids); (void)hipFree(x->d_fb_dist);
-    if (x->h_flags) (void)hipHostFree(x->h_flags);
+    (void)hipFree(x->d_counters); (void)hipFree(x->d_fb_partial);
+    if (x->h_counters) (void)hipHostFree(x->h_counters);
     (void)hipFree(x->d_norm_range);
     delete x;
     return 0;
@@ -478,6 +476,12 @@ const char* vq_index_profile_class_name(int cls) {
 
 int vq_index_last_search_stats(vq_index* x, int64_t* stats) {
     VQ_CHECK(x && stats, "vq_index_last_search_stats: null argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->stats_pending) {                    // the fp16 path's counters follow the search on its stream
+        VQ_HIP(hipStreamSynchronize(x->stream));
+        for (int i = 0; i < 3; ++i) x->stats[i] = x->h_counters[1 + i];
+        x->stats_pending = false;
+    }
     for (int i = 0; i < 3; ++i) stats[i] = x->stats[i];
     return 0;
 }
