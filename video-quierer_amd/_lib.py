@@ -14,7 +14,8 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvq_amd.so")
+# $VQ_AMD_LIB: another build of the same library (A/B timing of kernels on one GPU box)
+LIB_PATH = os.environ.get("VQ_AMD_LIB") or os.path.join(_HERE, "lib", "libvq_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ENC_NCLASS = 10

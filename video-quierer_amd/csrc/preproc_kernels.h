@@ -119,36 +119,66 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
     }
 }
 
-// Vertical pass (ImagingResampleVertical_8bpc): the weights of an output row are workgroup-uniform.  A thread
-// produces VEC consecutive bytes of one output row (VEC = 4 when rows are dword-aligned, else 1).
-// tmp [n][rows_in][row_bytes], dst [n][out_rows][row_bytes] for output rows [row_first, row_first + out_rows);
-// `row_shift` is the source row that tmp row 0 corresponds to.
+// Vertical pass (ImagingResampleVertical_8bpc).  A thread produces VEC consecutive bytes of one output row: 16 when
+// rows are 16-byte aligned (one wide load per tap, all taps independent: the pass is latency-bound on its ~11 taps),
+// else 4 or 1.  tmp [n][rows_in][row_bytes], dst [n][out_rows][row_bytes] for output rows [row_first, row_first +
+// out_rows); `row_shift` is the source row that tmp row 0 corresponds to.
+// Each clipped byte goes through an opaque register move before packing: ROCm 7.2's backend otherwise folds
+// clamp(x >> 22) pairs into v_ashr_pk_u8_i32, whose upper destination half it does not clear (bytes 2-3 of the
+// packed dword came out as stale register contents on gfx950).
+__device__ __forceinline__ uint32_t rs_pack4(int s0, int s1, int s2, int s3) {
+    uint32_t b0 = rs_clip8(s0), b1 = rs_clip8(s1), b2 = rs_clip8(s2), b3 = rs_clip8(s3);
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(RS_THREADS)
 void resample_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ dst,
                        const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
                        int rows_in, int row_bytes, int row_first, int out_rows, int row_shift) {
-    const int j = (blockIdx.x * RS_THREADS + threadIdx.x) * VEC;
-    const int yo = blockIdx.y, img = blockIdx.z;
-    if (j >= row_bytes) return;
+    const int img = blockIdx.z;
+    int j, yo;
+    if constexpr (VEC == 16) {                                      // threads cover (output row, 16-byte chunk) pairs
+        const int per_row = row_bytes >> 4;
+        const int idx = blockIdx.x * RS_THREADS + threadIdx.x;
+        yo = idx / per_row;
+        j = (idx - yo * per_row) << 4;
+        if (yo >= out_rows) return;
+    } else {
+        j = (blockIdx.x * RS_THREADS + threadIdx.x) * VEC;
+        yo = blockIdx.y;
+        if (j >= row_bytes) return;
+    }
     const int yy = row_first + yo;
     const int ymin = bounds[2 * yy] - row_shift, cnt = bounds[2 * yy + 1];
     const int* k = kk + (size_t)yy * ksize;
     const uint8_t* p = tmp + ((size_t)img * rows_in + ymin) * row_bytes + j;
     uint8_t* o = dst + ((size_t)img * out_rows + yo) * row_bytes + j;
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 16) {
+        int s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 1 << (RS_PRECISION_BITS - 1);
+        for (int t = 0; t < cnt; ++t) {
+            const uint4 v = *(const uint4*)(p + (size_t)t * row_bytes);
+            const int c = k[t];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                s[4 * d] += __mul24((int)(w4[d] & 255), c);             s[4 * d + 1] += __mul24((int)((w4[d] >> 8) & 255), c);
+                s[4 * d + 2] += __mul24((int)((w4[d] >> 16) & 255), c); s[4 * d + 3] += __mul24((int)(w4[d] >> 24), c);
+            }
+        }
+        *(uint4*)o = uint4{rs_pack4(s[0], s[1], s[2], s[3]), rs_pack4(s[4], s[5], s[6], s[7]),
+                           rs_pack4(s[8], s[9], s[10], s[11]), rs_pack4(s[12], s[13], s[14], s[15])};
+    } else if constexpr (VEC == 4) {
         int s0 = 1 << (RS_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
         for (int t = 0; t < cnt; ++t) {
             const uint32_t v = *(const uint32_t*)(p + (size_t)t * row_bytes);
             const int c = k[t];
             s0 += __mul24((int)(v & 255), c); s1 += __mul24((int)((v >> 8) & 255), c); s2 += __mul24((int)((v >> 16) & 255), c); s3 += __mul24((int)(v >> 24), c);
         }
-        // Each clipped byte goes through an opaque register move before packing: ROCm 7.2's backend otherwise
-        // folds clamp(x >> 22) pairs into v_ashr_pk_u8_i32, whose upper destination half it does not clear
-        // (bytes 2-3 of the packed dword came out as stale register contents on gfx950).
-        uint32_t b0 = rs_clip8(s0), b1 = rs_clip8(s1), b2 = rs_clip8(s2), b3 = rs_clip8(s3);
-        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-        *(uint32_t*)o = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        *(uint32_t*)o = rs_pack4(s0, s1, s2, s3);
     } else {
         int s = 1 << (RS_PRECISION_BITS - 1);
         for (int t = 0; t < cnt; ++t) s += __mul24((int)p[(size_t)t * row_bytes], k[t]);

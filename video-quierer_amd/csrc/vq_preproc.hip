@@ -234,7 +234,11 @@ int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int f
                            r->d_bh, r->d_kh, r->ch.ksize, h, w, row_first, rows_needed, crop_left, crop_w, oc, pitch_dw, tile_pitch);
     VQ_HIP(hipGetLastError());
     const int row_bytes = crop_w * 3;
-    if (row_bytes % 4 == 0 && ((uintptr_t)d_dst & 3) == 0) {
+    if (row_bytes % 16 == 0 && ((uintptr_t)d_dst & 15) == 0 && ((uintptr_t)r->tmp.p & 15) == 0) {
+        hipLaunchKernelGGL(resample_v_kernel<16>, dim3(cdiv((row_bytes / 16) * crop_h, RS_THREADS), 1, n), dim3(RS_THREADS), 0, r->stream,
+                           (const uint8_t*)r->tmp.p, d_dst, r->d_bv, r->d_kv, r->cv.ksize, rows_needed, row_bytes, crop_top,
+                           crop_h, row_first);
+    } else if (row_bytes % 4 == 0 && ((uintptr_t)d_dst & 3) == 0) {
         hipLaunchKernelGGL(resample_v_kernel<4>, dim3(cdiv(row_bytes / 4, RS_THREADS), crop_h, n), dim3(RS_THREADS), 0, r->stream,
                            (const uint8_t*)r->tmp.p, d_dst, r->d_bv, r->d_kv, r->cv.ksize, rows_needed, row_bytes, crop_top,
                            crop_h, row_first);
