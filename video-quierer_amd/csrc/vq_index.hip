@@ -6,6 +6,7 @@
 #include "knn_kernels.h"
 #include "knn_scan_f16.h"
 #include "knn_fallback.h"
+#include "knn_scan_deep.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -49,7 +50,7 @@ struct vq_index {
     uint32_t* d_norm_range = nullptr;
     bool norm_dirty = false, near_unit = true;
     float row_norm_max = 1.0f;
-    int scan_version = 2;          // $VQ_AMD_SCAN: 2 = 256x256 phased mainloop (needs dim % 128 == 0), 1 = 128x128
+    int scan_version = 4;          // $VQ_AMD_SCAN: 4 = 256x256 deep-prefetch mainloop (needs dim % 128 == 0), 2 = 256x256 four-phase, 1 = 128x128
     bool no_small_scan = false;    // $VQ_AMD_SCAN_SMALL=0: batches of <= 64 queries also take the MFMA-tile scan (A/B switch)
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -168,8 +169,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // streaming scan; the 256-query MFMA tile is for batches
     const bool small = nq <= SCAN3_MAX_Q && (x->dim == 512 || x->dim == 256) && !x->no_small_scan;
     const int ver = small ? 3 : x->scan_version;                       // 3: streaming, 2: 256x256 phased mainloop, 1: 128x128
-    const int QT = ver == 3 ? SCAN3_QB : ver == 2 ? SCAN2_QT : SCAN_QT;
-    const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver == 2 ? SCAN2_RANGE : SCAN_RANGE;
+    const int QT = ver == 3 ? SCAN3_QB : ver >= 2 ? SCAN2_QT : SCAN_QT;
+    const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver >= 2 ? SCAN2_RANGE : SCAN_RANGE;
     const int64_t n_pad = round_up(n, RANGE);
     const int64_t streams = n_pad / SCAN_STREAM_ROWS;
     const int64_t key_budget = (int64_t)1 << 27;                       // 128 Mi (stream,query) pairs = 1 GiB of keys
@@ -197,11 +198,13 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             attr3_set = true;
         }
     }
-    if (ver == 2) {
+    if (ver == 2 || ver == 4) {
         static bool attr_set = false;
         if (!attr_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)scan2_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G2_LDS_BYTES));
+            VQ_HIP(hipFuncSetAttribute((const void*)scan4_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SCAN4_LDS_BYTES));
             attr_set = true;
         }
     }
@@ -225,10 +228,14 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
                 else
                     hipLaunchKernelGGL(scan3_f16_top2_kernel<8>, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams,
                                        q_pad, x->d_keys);
-            } else if (ver == 2) {
+            } else if (ver == 2 || ver == 4) {
                 const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
-                hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), G2_LDS_BYTES,
-                                   x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
+                if (ver == 4)
+                    hipLaunchKernelGGL(scan4_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
+                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
+                else
+                    hipLaunchKernelGGL(scan2_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), G2_LDS_BYTES,
+                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
             }
             else
                 hipLaunchKernelGGL(scan_f16_top2_kernel, dim3(q_tiles * ranges), dim3(GEMM_THREADS), 0, x->stream, x->d_q16,
@@ -243,7 +250,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                               d_dist_out + q0 * k, x->d_flags + q0, ver, scan_eps_unit(x->dim) * x->row_norm_max);
+                               d_dist_out + q0 * k, x->d_flags + q0, ver == 4 ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
         }
     }
     VQ_HIP(hipGetLastError());
@@ -313,7 +320,7 @@ int vq_index_create(int dim, vq_index** out) {
     VQ_CHECK(out && dim > 0 && dim % 4 == 0 && dim <= 4096, "vq_index_create: dim %d must be a positive multiple of 4", dim);
     vq_index* x = new vq_index();
     x->dim = dim;
-    if (const char* sv = getenv("VQ_AMD_SCAN")) x->scan_version = atoi(sv) == 1 ? 1 : 2;
+    if (const char* sv = getenv("VQ_AMD_SCAN")) { const int v = atoi(sv); x->scan_version = (v == 1 || v == 2) ? v : 4; }
     if (dim % 128 != 0) x->scan_version = 1;
     if (const char* ss = getenv("VQ_AMD_SCAN_SMALL")) x->no_small_scan = atoi(ss) == 0;
     hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
