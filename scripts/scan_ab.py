@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex, MODE_FP16
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(7)
 idx = OptimizedHNSWIndex(dimension=512)
@@ -17,20 +18,20 @@ for c0 in range(0, n, 250_000):
     idx.add_device(blk.data_ptr(), c, range(c0, c0 + c), normalize=True)
     idx.synchronize()
 q = torch.randn((nq, 512), device=dev, generator=g); q = q / q.norm(dim=1, keepdim=True)
-ids = torch.empty((nq, 10), dtype=torch.int32, device=dev); dd = torch.empty((nq, 10), device=dev)
+ids = torch.empty((nq, K), dtype=torch.int32, device=dev); dd = torch.empty((nq, K), device=dev)
 torch.cuda.synchronize()
 for _ in range(2):
-    idx.search_device(q.data_ptr(), nq, 10, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
+    idx.search_device(q.data_ptr(), nq, K, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
 idx.synchronize()
 import time
 t0 = time.perf_counter()
 for _ in range(5):
-    idx.search_device(q.data_ptr(), nq, 10, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
+    idx.search_device(q.data_ptr(), nq, K, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
 idx.synchronize()
 wall = (time.perf_counter() - t0) / 5
 idx.profile_begin()
 for _ in range(5):
-    idx.search_device(q.data_ptr(), nq, 10, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
+    idx.search_device(q.data_ptr(), nq, K, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
 prof = {k: round(v["ms"] / 5, 4) for k, v in idx.profile_end().items() if v["launches"]}
-print(f"VQ_AMD_SCAN={os.environ.get('VQ_AMD_SCAN', 'default')} N={n} Q={nq}: {wall*1e3:.3f} ms per batch = {nq/wall:.0f} q/s; kernels {prof}; "
+print(f"VQ_AMD_SCAN={os.environ.get('VQ_AMD_SCAN', 'default')} N={n} Q={nq} k={K}: {wall*1e3:.3f} ms per batch = {nq/wall:.0f} q/s; kernels {prof}; "
       f"stats {idx.last_search_stats()}; checksum {int(ids.long().sum())} {float(dd.double().sum()):.9f}")

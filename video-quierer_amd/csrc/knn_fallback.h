@@ -21,8 +21,10 @@ constexpr int FB_QG = 8;          // flagged queries per row pass
 constexpr int FB_TILE = 256;      // rows per tile = threads per workgroup
 constexpr int FB_PANEL = 32;      // dims per LDS panel
 constexpr int FB_KMAX = 32;       // k of the fp16 path (RV_C)
-constexpr int FB_SPLIT_ROWS = 2048;
-constexpr int FB_MAX_SPLITS = 1024;
+constexpr int FB_SPLIT_ROWS = 2048;   // rows per workgroup of the bulk rounds
+constexpr int FB_FAST_ROWS = 512;     // ... of the first round (the first FB_FAST_SLOTS flagged queries: the normal case is a handful)
+constexpr int FB_FAST_SLOTS = 64;
+constexpr int FB_MAX_SPLITS = 4096;
 constexpr int FB_SLOT_LANES = 2;
 // device counters: [0] flagged queries, [1..3] outcome counts (proven, proven after rescans, exact fallback)
 constexpr int FB_NCOUNTERS = 4;
@@ -85,25 +87,39 @@ void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
         }
         for (int i = tid; i < FB_QG * FB_KMAX; i += FB_TILE) best[0][i / FB_KMAX][i % FB_KMAX] = ~0ull;
         __syncthreads();
+        // panels of FB_PANEL dims, software-pipelined: the next panel's rows and query values are loaded into registers
+        // while the current one is multiplied out of LDS (a workgroup has few waves: an exposed load per panel made
+        // the scan of one flagged query take ~1 ms)
+        const int np = dim / FB_PANEL;
+        const int j_q = tid >> 5, c_q = tid & 31;
+        float4 nx[FB_TILE * FB_PANEL / 4 / FB_TILE];
+        double nqv = 0.0;
+        auto load_panel = [&](int64_t r0, int d0) {
+#pragma unroll
+            for (int u = 0; u < FB_TILE * FB_PANEL / 4 / FB_TILE; ++u) {
+                const int idx = tid + FB_TILE * u, rr = idx >> 3, c4 = (idx & 7) * 4;
+                const int64_t gr = r0 + rr;
+                nx[u] = float4{0.f, 0.f, 0.f, 0.f};
+                if (gr < r_end) nx[u] = *(const float4*)(rows + gr * dim + d0 + c4);      // dim % FB_PANEL == 0 (host check)
+            }
+            const int q = qidx[j_q];
+            nqv = q >= 0 ? (double)queries[(int64_t)q * dim + d0 + c_q] : 0.0;
+        };
+        if (r_begin < r_end) load_panel(r_begin, 0);
         for (int64_t r0 = r_begin; r0 < r_end; r0 += FB_TILE) {
             double acc[FB_QG];
 #pragma unroll
             for (int j = 0; j < FB_QG; ++j) acc[j] = 0.0;
-            for (int d0 = 0; d0 < dim; d0 += FB_PANEL) {
+            for (int pi = 0; pi < np; ++pi) {
 #pragma unroll
                 for (int u = 0; u < FB_TILE * FB_PANEL / 4 / FB_TILE; ++u) {
                     const int idx = tid + FB_TILE * u, rr = idx >> 3, c4 = (idx & 7) * 4;
-                    const int64_t gr = r0 + rr;
-                    float4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < r_end) v = *(const float4*)(rows + gr * dim + d0 + c4);      // dim % FB_PANEL == 0 (host check)
-                    xs[rr][c4] = v.x; xs[rr][c4 + 1] = v.y; xs[rr][c4 + 2] = v.z; xs[rr][c4 + 3] = v.w;
+                    xs[rr][c4] = nx[u].x; xs[rr][c4 + 1] = nx[u].y; xs[rr][c4 + 2] = nx[u].z; xs[rr][c4 + 3] = nx[u].w;
                 }
-                {
-                    const int j = tid >> 5, c = tid & 31;
-                    const int q = qidx[j];
-                    qs[c][j] = q >= 0 ? (double)queries[(int64_t)q * dim + d0 + c] : 0.0;
-                }
+                qs[c_q][j_q] = nqv;
                 __syncthreads();
+                if (pi + 1 < np) load_panel(r0, (pi + 1) * FB_PANEL);
+                else if (r0 + FB_TILE < r_end) load_panel(r0 + FB_TILE, 0);
 #pragma unroll 4
                 for (int c = 0; c < FB_PANEL; ++c) {
                     const double xv = (double)xs[tid][c];
@@ -113,13 +129,20 @@ void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
                 __syncthreads();
             }
             const int64_t row = r0 + tid;
-            if (row < r_end) {
+            // rows that beat the query's current k-th key join its candidate list: one LDS atomic per wave and query
+            // (a wave-wide ballot places the lanes), not one per row — the first tiles of a scan accept every row
 #pragma unroll
-                for (int j = 0; j < FB_QG; ++j) {
-                    if (qidx[j] < 0) continue;
-                    const uint64_t key = dist_key(1.0f - (float)acc[j], (uint32_t)row);
-                    if (key < best[cur_s[j]][j][k - 1]) cand[j][atomicAdd(&cand_n[j], 1)] = key;
-                }
+            for (int j = 0; j < FB_QG; ++j) {
+                if (qidx[j] < 0) continue;                                           // block-uniform
+                const uint64_t key = dist_key(1.0f - (float)acc[j], (uint32_t)row);
+                const bool in = row < r_end && key < best[cur_s[j]][j][k - 1];
+                const unsigned long long mask = __ballot(in);
+                if (mask == 0) continue;                                             // wave-uniform
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&cand_n[j], __builtin_popcountll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (in) cand[j][base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
             }
             __syncthreads();
             // fold the tile's candidates into the k best so far: rank counting over (list + candidates); keys are
@@ -151,32 +174,39 @@ void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
     }
 }
 
+// k-way merge of the per-split lists (each ascending): the current head of every list sits in LDS; a round takes the
+// smallest head (block minimum; keys are unique: the row is in the key) and only the thread that owns that list
+// fetches its next key.  (Re-reading all splits*k keys in each of the k rounds made this 2.3 ms for ONE query.)
 __global__ __launch_bounds__(256)
 void fallback_merge_kernel(const uint64_t* __restrict__ partial, int splits, int k, const int32_t* __restrict__ slots,
                            const int32_t* __restrict__ counters, int slot_base, int slot_cap,
                            int32_t* __restrict__ ids, float* __restrict__ out_dist) {
     __shared__ uint64_t red[4];
+    __shared__ uint64_t head[FB_MAX_SPLITS];
+    __shared__ uint8_t pos[FB_MAX_SPLITS];
     const int count = min(counters[0] - slot_base, slot_cap);
     const int tid = threadIdx.x;
     for (int s = blockIdx.x; s < count; s += gridDim.x) {
         const int q = slots[slot_base + s];
         const uint64_t* p = partial + (int64_t)s * splits * k;
-        const int total = splits * k;
-        uint64_t prev = 0;
+        __syncthreads();                                   // the previous query's rounds are over
+        for (int l = tid; l < splits; l += 256) { head[l] = p[(int64_t)l * k]; pos[l] = 0; }
+        __syncthreads();
         for (int j = 0; j < k; ++j) {
-            uint64_t b = ~0ull;
-            for (int i = tid; i < total; i += 256) {
-                const uint64_t key = p[i];
-                if ((j == 0 || key > prev) && key < b) b = key;
+            uint64_t mine = ~0ull; int ml = -1;
+            for (int l = tid; l < splits; l += 256) { const uint64_t h = head[l]; if (h < mine) { mine = h; ml = l; } }
+            const uint64_t b = block_min_u64(mine, red, tid);
+            if (b != ~0ull && mine == b) {                 // exactly one thread: advance the winning list
+                const int np = pos[ml] + 1;
+                pos[ml] = (uint8_t)np;
+                head[ml] = np < k ? p[(int64_t)ml * k + np] : ~0ull;
             }
-            b = block_min_u64(b, red, tid);
             if (tid == 0) {
                 const int64_t o = (int64_t)q * k + j;
                 if (b == ~0ull) { ids[o] = -1; out_dist[o] = __builtin_inff(); }
                 else { ids[o] = (int32_t)(uint32_t)b; out_dist[o] = key_dist(b); }
             }
-            prev = b;
-            if (b == ~0ull) {
+            if (b == ~0ull) {                              // every list exhausted (block-uniform)
                 for (int jj = j + 1 + tid; jj < k; jj += 256) { ids[(int64_t)q * k + jj] = -1; out_dist[(int64_t)q * k + jj] = __builtin_inff(); }
                 break;
             }

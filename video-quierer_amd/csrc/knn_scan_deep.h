@@ -19,7 +19,7 @@ constexpr int SCAN4_LDS_BYTES = G2_LDS_BYTES + 8 * 8 * 64 * 8;      // + the run
 __global__ __launch_bounds__(G2_THREADS, 2)
 void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
                            int dim, int64_t n_valid, int q_tiles, int n_ranges, int range_groups, int64_t q_pad,
-                           uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,7 +217,7 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     for (int mi = 0; mi < 8; ++mi) {
         const int q = m0 + wr * 128 + mi * 16 + frow;
         const float2 p = mm[mi * 64];
-        *(uint2*)(keys + ((size_t)stream * q_pad + q) * 2) = uint2{__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y)};
+        *(uint2*)(keys + batch_key_index(stream, q, (int64_t)n_ranges * 16)) = uint2{__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y)};
     }
 }
 

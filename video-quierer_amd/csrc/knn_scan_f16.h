@@ -12,14 +12,14 @@
 //   t*16 + ni*4 + r (7 bits) stored in the low mantissa bits of the score.
 //   Output: keys[stream][query][2] (fp32 bit patterns), 8 B per (stream, query).
 //
-// Pass 2  rescore_verify_kernel  (16 queries per workgroup)
-//   per query: keep the best 8 keys of each of 16 interleaved stream shares,
+// Pass 2  rescore_verify_kernel  (RV_QPW = 8 queries per workgroup)
+//   per query: keep the best 4 keys of each of 32 interleaved stream shares,
 //   take the best C=32 of those 128, re-score them EXACTLY from the fp32 master
 //   (fixed-order fp64 chain, bit-identical to oracle/knn_oracle.c), and prove the
 //   result: with s_k the k-th best exact score and EPS the worst-case fp16
 //   scoring error, every row that was NOT re-scored has an upper bound
 //     - rows a stream did not emit        <= that stream's 2nd key
-//     - keys a share dropped              <= that share's 8th kept key
+//     - keys a share dropped              <= the largest key that share dropped
 //     - kept keys outside the best C      <= the (C+1)-th kept key
 //   If a stream's 2nd key could still matter (key + EPS >= s_k) its 128 rows are
 //   re-scored exactly too (up to RESCAN_MAX streams).  If a bound cannot be
@@ -49,6 +49,14 @@ static inline float scan_eps_unit(int dim) {
     return (float)(e * 1.02);
 }
 
+// Key layout of the batch scans: [group of 16 queries][stream][16 queries][2 keys].  A scan lane group writes the
+// 128 bytes of (stream, 16 queries) at once, and the re-score workgroup of a query group walks its streams through
+// CONTIGUOUS memory (stream-major [stream][q_pad] made every one of its reads a 64-128 byte piece of a different
+// 80 KB row: the pass moved 0.67 GB at ~0.7 TB/s).  The streaming scan for <= 64 queries keeps [stream][q_pad].
+__host__ __device__ inline size_t batch_key_index(int64_t stream, int64_t q, int64_t streams) {
+    return (((size_t)(q >> 4) * streams + stream) * 16 + (q & 15)) * 2;
+}
+
 // row number of (stream, local index)
 __host__ __device__ inline int64_t scan_row_of(int64_t stream, int local) {
     const int64_t range = stream >> 3;
@@ -60,7 +68,7 @@ __host__ __device__ inline int64_t scan_row_of(int64_t stream, int local) {
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
                           int dim, int64_t n_valid, int q_tiles, int64_t q_pad,
-                          uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+                          uint32_t* __restrict__ keys /*batch_key_index*/) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
@@ -170,7 +178,7 @@ void scan_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __re
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int q = m0 + wm * 64 + mi * 16 + frow;
-        *(uint2*)(keys + ((size_t)stream * q_pad + q) * 2) =
+        *(uint2*)(keys + batch_key_index(stream, q, (int64_t)(gridDim.x / q_tiles) * 8)) =
             uint2{__builtin_bit_cast(uint32_t, m1[mi]), __builtin_bit_cast(uint32_t, m2[mi])};
     }
 }
@@ -378,7 +386,7 @@ void scan2_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int q = m0 + wr * 128 + mi * 16 + frow;
-        *(uint2*)(keys + ((size_t)stream * q_pad + q) * 2) =
+        *(uint2*)(keys + batch_key_index(stream, q, (int64_t)n_ranges * 16)) =
             uint2{__builtin_bit_cast(uint32_t, m1[mi]), __builtin_bit_cast(uint32_t, m2[mi])};
     }
 }
@@ -398,9 +406,12 @@ void queries_to_f16_kernel(const float* __restrict__ q, uint16_t* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------
-constexpr int RV_QPW = 16;        // queries per workgroup
-constexpr int RV_KEEP = 8;        // keys kept per (query, share)
-constexpr int RV_SHARES = 16;     // stream shares per query (thread = (query, share))
+constexpr int RV_QPW = 8;         // queries per workgroup (16 needed 90 KB of LDS, mostly the rescan pool: one workgroup per CU; 8 -> three)
+constexpr int RV_KEEP = 6;        // keys kept per (query, share).  A wave runs the insertion path whenever ANY of its lanes inserts (most offers), so its
+                                  // length sets the cost of phase 1: 8 -> 0.96 ms per 10k queries, 6 -> 0.74, 4 -> 0.71 but then ~3 queries in 10,000 leave
+                                  // a bound open (a share holding 5 of the best ~11 keys) and go to the exact fallback
+constexpr int RV_SHARES = 256 / RV_QPW;   // stream shares per query (thread = (query, share))
+constexpr int RV_TPQ = 256 / RV_QPW;      // threads per query in the selection phases
 constexpr int RV_C = 32;          // candidates re-scored exactly
 constexpr int RV_RESCAN_MAX = 4;  // streams re-scored per query before giving up
 constexpr int RV_POOL = RV_C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;   // exact-scored rows per query
@@ -441,7 +452,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     __shared__ float qn2[RV_QPW][RV_SHARES];                   // partial |q|^2 (the bound scales with |q|)
 
     const int tid = threadIdx.x;
-    const int ql = tid & 15, share = tid >> 4;
+    const int ql = tid % RV_QPW, share = tid / RV_QPW;
     const int q0 = blockIdx.x * RV_QPW;
     const int q = q0 + ql;
     const float NEG = -__builtin_inff();
@@ -469,7 +480,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     for (; s + (PF - 1) * RV_SHARES < streams; s += PF * RV_SHARES) {
         uint2 two[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + ((size_t)(s + u * RV_SHARES) * q_pad + q) * 2);   // 16 lanes: 128 B contiguous
+        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + batch_key_index(s + u * RV_SHARES, q, streams));   // a wave: 8 adjacent 128-byte blocks
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int src = (int)((s + u * RV_SHARES) * 2);
@@ -478,7 +489,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         }
     }
     for (; s < streams; s += RV_SHARES) {
-        const uint2 two = *(const uint2*)(keys + ((size_t)s * q_pad + q) * 2);
+        const uint2 two = *(const uint2*)(keys + batch_key_index(s, q, streams));
         offer(__builtin_bit_cast(float, two.x), (int)(s * 2));
         offer(__builtin_bit_cast(float, two.y), (int)(s * 2 + 1));
     }
@@ -491,8 +502,8 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     // ---- 2. per query (one 16-lane group each): the best C of the 128 kept keys, by rank counting ----
     //      rank(i) = #{j : v_j > v_i or (v_j == v_i and j < i)}; unique ranks 0..127
     {
-        const int qq = tid >> 4, l16 = tid & 15;               // 16 threads per query here
-        for (int i = l16; i < RV_SHARES * RV_KEEP; i += 16) {
+        const int qq = tid / RV_TPQ, l16 = tid % RV_TPQ;       // RV_TPQ threads per query here
+        for (int i = l16; i < RV_SHARES * RV_KEEP; i += RV_TPQ) {
             const float vi = kept_v[qq][i];
             int rank = 0;
             for (int j = 0; j < RV_SHARES * RV_KEEP; ++j) {
@@ -591,21 +602,21 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
 
     // ---- 6. final exact top-k of the pool by (distance, row); duplicates collapse (same key) ----
     {
-        const int qq = tid >> 4, l16 = tid & 15;
+        const int qq = tid / RV_TPQ, l16 = tid % RV_TPQ;
         if (q0 + qq < nq) {
             const int pn = pool_n[qq];
             if (l16 == 0) flags[q0 + qq] = state[qq];
             uint64_t prev = 0; bool have_prev = false;
             for (int j = 0; j < k; ++j) {
                 uint64_t best = ~0ull;
-                for (int i = l16; i < pn; i += 16) {
+                for (int i = l16; i < pn; i += RV_TPQ) {
                     if (cand_row[qq][i] < 0) continue;
                     const uint64_t key = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
                     if ((!have_prev || key > prev) && key < best) best = key;
                 }
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const uint64_t other = __shfl_xor(best, o, 16);
+                for (int o = RV_TPQ / 2; o > 0; o >>= 1) {
+                    const uint64_t other = __shfl_xor(best, o, RV_TPQ);
                     best = other < best ? other : best;
                 }
                 if (l16 == 0) {
@@ -615,7 +626,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                 }
                 prev = best; have_prev = true;
                 if (best == ~0ull) {
-                    for (int jj = j + 1 + l16; jj < k; jj += 16) {
+                    for (int jj = j + 1 + l16; jj < k; jj += RV_TPQ) {
                         out_ids[(size_t)(q0 + qq) * k + jj] = -1; out_dist[(size_t)(q0 + qq) * k + jj] = __builtin_inff();
                     }
                     break;

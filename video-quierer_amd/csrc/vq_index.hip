@@ -184,11 +184,15 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         VQ_HIP(hipMalloc((void**)&x->d_counters, FB_NCOUNTERS * 4));
         VQ_HIP(hipHostMalloc((void**)&x->h_counters, FB_NCOUNTERS * 4));
     }
-    // row splits of the fallback scan and how many flagged queries one round of it may take (scratch <= 64 MiB)
+    // Device-side fallback geometry.  First round: the first FB_FAST_SLOTS flagged queries over fine row splits (many
+    // short workgroups: the usual handful of unproven queries is back in ~0.1 ms); bulk rounds: the rest over coarse
+    // splits, as many flagged queries per round as 64 MiB of per-split lists hold.  One scratch buffer serves both.
+    const int fast_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_FAST_ROWS)));
+    const int64_t fast_rows = round_up(cdiv(n, fast_splits), FB_TILE);
     const int fb_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_SPLIT_ROWS)));
     const int64_t fb_rows = round_up(cdiv(n, fb_splits), FB_TILE);
     const int64_t fb_cap = std::max<int64_t>(FB_QG, std::min<int64_t>(round_up(nq, FB_QG), ((int64_t)64 << 20) / ((int64_t)fb_splits * k * 8) / FB_QG * FB_QG));
-    VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, fb_cap * fb_splits * k));
+    VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, std::max<int64_t>(fb_cap * fb_splits, (int64_t)FB_FAST_SLOTS * fast_splits) * k));
     const int ranges = (int)(n_pad / RANGE);
     if (ver == 3) {
         static bool attr3_set = false;
@@ -261,7 +265,11 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
     {
         Prof p(x, I_EXACT_DIST);
-        for (int64_t base = 0; base < nq; base += fb_cap) {
+        hipLaunchKernelGGL(exact_fallback_kernel, dim3(fast_splits, 1), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
+                           d_queries, x->d_slots, x->d_counters, 0, FB_FAST_SLOTS, k, fast_rows, x->d_fb_partial);
+        hipLaunchKernelGGL(fallback_merge_kernel, dim3(FB_FAST_SLOTS), dim3(256), 0, x->stream, x->d_fb_partial, fast_splits, k, x->d_slots,
+                           x->d_counters, 0, FB_FAST_SLOTS, d_ids, d_dist_out);
+        for (int64_t base = FB_FAST_SLOTS; base < nq; base += fb_cap) {
             hipLaunchKernelGGL(exact_fallback_kernel, dim3(fb_splits, FB_SLOT_LANES), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
                                d_queries, x->d_slots, x->d_counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial);
             hipLaunchKernelGGL(fallback_merge_kernel, dim3(64), dim3(256), 0, x->stream, x->d_fb_partial, fb_splits, k, x->d_slots,
