@@ -321,7 +321,7 @@ def main():
         # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
         # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/, gfx950 correction applied there)
         traffic, tsrc = None, None
-        for cand in ("r02_pmc_traffic.json", "r01d_pmc_traffic.json"):
+        for cand in ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
@@ -392,7 +392,8 @@ def main():
         srch = {"value": qps, "unit": "queries/s", "rows": n_rows * world, "dim": dimq, "queries": nq, "k": k,
                 "ms_per_batch": 1e3 * s_batch,
                 "mode": "auto: fp16 MFMA scan with per-stream top-2 + exact fp64-chain re-score and proof; "
-                        "unproven queries redone by the exact fp32-master scan",
+                        "unproven queries redone by the exact fp32-master scan on the device (no flag read-back: the "
+                        "search is asynchronous on its stream)",
                 "sharding": f"{world} row shards + all-gather of local top-k ({exchange})" if world > 1 else "single GPU",
                 # a 10k-query batch is MFMA-bound (2*Q*N*D flops); the fraction is end to end
                 # (query conversion + scan + re-score + flags), the scan kernel alone is in kernel_classes
@@ -420,8 +421,17 @@ def main():
             srch["kernel_classes"] = {k_: v for k_, v in sp.items() if v["launches"]}
             scan_ms = sp.get("scan_f16_mfma_top2", {}).get("ms", 0.0)
             if scan_ms > 0:
+                scan_traffic = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r02b_pmc_traffic.json")) as f:
+                        scan_traffic = json.load(f)["kernels"].get("scan_f16_mfma_top2", {}).get("hbm_bytes")
+                except OSError:
+                    pass
                 srch["roofline"]["scan_kernel"] = {"ms": scan_ms, "achieved": 2.0 * nq * n_rows * dimq / (scan_ms * 1e-3) / 1e12,
-                                                   "frac": 2.0 * nq * n_rows * dimq / (scan_ms * 1e-3) / PEAK_FP16}
+                                                   "frac": 2.0 * nq * n_rows * dimq / (scan_ms * 1e-3) / PEAK_FP16,
+                                                   # bytes from beyond L2 per launch (rocprofv3 PMC, 10k x 1M x 512): the matrix
+                                                   # is 1.02 GB, each 256-query tile re-streams it from L2 / Infinity Cache
+                                                   "traffic": scan_traffic}
             srch["last_search_stats"] = idx.last_search_stats()
         # CPU baselines for the search leg (rank 0, N=1 only), over the SAME matrix: what a CPU user would run
         # (numpy sgemm brute force, the reference's live path video_search_overhaul.py:54 np.dot + argsort), the exact

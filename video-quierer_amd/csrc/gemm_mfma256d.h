@@ -274,6 +274,12 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
 //
 // Every unit is re-issued two phases after its last read (WAR) and awaited one phase before its first read (RAW),
 // exactly as in the four-phase schedule above; the waits are vmcnt(6) / vmcnt(2) in steady state.
+//
+// Staging is `buffer_load ... lds` with FOUR lane-offset registers (piece 2w of unit 0 of each operand and the same
+// ^ 64 for piece 2w+1, whose swizzle differs by chunk ^ 4; unit / piece row offsets and the K offset are scalar).  The
+// first build of this schedule kept eight 64-bit source pointers per lane, three of which the register allocator
+// spilled and RELOADED INSIDE THE K LOOP: a scratch load waits vmcnt(0), i.e. for every LDS-DMA unit in flight, so
+// what was measured (and rejected) in round 2 was the spill, not the schedule.  Requires lda, ldw % 64 == 0.
 template <bool IS_F16, class Epi>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
@@ -294,34 +300,28 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
     const int m0 = tm * G2_BM;
     const int n0 = tn * G2_BN;
 
+    // A unit hm: piece p -> rows (p>>3)*128 + hm*64 + (p&7)*8 ..+7;  W unit hn: piece p -> rows (p>>2)*64 + hn*32 + (p&3)*8 ..+7
     const int srow = lane >> 3, sslot = lane & 7;
-    const uint16_t* a_src[2][2];
-    const uint16_t* w_src[2][2];
-    int a_dst[2][2], w_dst[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = wave * 2 + i;
-            const int arow0 = (p >> 3) * 128 + h * 64 + (p & 7) * 8;
-            const int wrow0 = (p >> 2) * 64 + h * 32 + (p & 3) * 8;
-            const int ar = arow0 + srow, wrw = wrow0 + srow;
-            a_src[h][i] = A + (size_t)(m0 + ar) * lda + (sslot ^ ((ar >> 1) & 7)) * 8;
-            w_src[h][i] = W + (size_t)(n0 + wrw) * ldw + (sslot ^ ((wrw >> 1) & 7)) * 8;
-            a_dst[h][i] = arow0 * 128;
-            w_dst[h][i] = 2 * G2_HALF + wrow0 * 128;
-        }
-    auto stage_a = [&](int buf, int hm, int kt) {
-        char* base = smem + buf * G2_BUF;
-        const int koff = kt * G2_BK;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
+    const int arow_w = (wave >> 2) * 128 + (wave & 3) * 16, wrow_w = (wave >> 1) * 64 + (wave & 1) * 16;   // piece 2w of unit 0
+    const int ar = arow_w + srow, wrw = wrow_w + srow;
+    const int a_v0 = (ar * lda + (sslot ^ ((ar >> 1) & 7)) * 8) * 2, a_v1 = a_v0 ^ 64;
+    const int w_v0 = (wrw * ldw + (sslot ^ ((wrw >> 1) & 7)) * 8) * 2, w_v1 = w_v0 ^ 64;
+    const int a_dst0 = arow_w * 128, w_dst0 = 2 * G2_HALF + wrow_w * 128;
+    const int a_row8 = 8 * lda * 2, w_row8 = 8 * ldw * 2;                  // 8 source rows, bytes
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, 0x7fffffff, 0x00020000);
+
+    auto stage_a = [&](int buf, int hm, int kt) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + a_dst0 + hm * (64 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(kt * (G2_BK * 2) + hm * 8 * a_row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base), 16, a_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + 1024), 16, a_v1, soff + a_row8, 0, 0);
     };
-    auto stage_w = [&](int buf, int hn, int kt) {
-        char* base = smem + buf * G2_BUF;
-        const int koff = kt * G2_BK;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
+    auto stage_w = [&](int buf, int hn, int kt) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + w_dst0 + hn * (32 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(kt * (G2_BK * 2) + hn * 4 * w_row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + w_row8, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -338,21 +338,21 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
     frag af[4][2], wf[4][2];             // one A sub-block (64 rows); the wave's whole W block (64 cols)
 
     const int nk = K / G2_BK;
-    auto load_a = [&](const char* buf, int hm) {
+    auto load_a = [&](const char* buf, int hm) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
     };
-    auto load_w = [&](const char* buf) {
+    auto load_w = [&](const char* buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 wf[j][ks] = *(const frag*)(buf + w_base + j * 2048 + slot[ks]);
     };
-    auto mfma_half = [&](int hm) {
+    auto mfma_half = [&](int hm) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -363,14 +363,14 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
                     acc[hm * 4 + i][j] = op::run(wf[j][ks], af[i][ks], acc[hm * 4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto barrier = [&]() {
+    auto barrier = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 #define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-    auto tile = [&](int kt, int bufi) {
+    auto tile = [&](int kt, int bufi) __attribute__((always_inline)) {
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < nk;
         // phase A: rows 0..63 of the wave's tile x all 64 columns
@@ -391,6 +391,8 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
     };
 
     stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
+    // (mean, rstd) of the tile's rows for LayerNorm-consuming epilogues, while the first units are in flight
+    const Epi epi_wg = epi_bind_rowstats<G2_BM>(epi, (float2*)(smem + G2_LDS_BYTES), m0, tid, G2_THREADS);
     VQ_VMCNT(2);
     barrier();
 
@@ -403,30 +405,28 @@ void gemm_tn256e_kernel(const uint16_t* __restrict__ A, int lda,
     barrier();
 #undef VQ_VMCNT
 
-    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi);
+    wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi_wg);
 }
 
 template <bool IS_F16, class Epi>
 static int launch_gemm_tn256e(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                               int M, int N, int K, const Epi& epi) {
-    if constexpr (epi_row_in<Epi>::value) return fail(VQ_ERR_INVALID, "gemm_tn256e: LayerNorm-consuming epilogues run on the 256d / 128 kernels only");
-    else {
     VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0,
              "gemm_tn256e: shape M=%d N=%d K=%d is not tile-aligned (256/256/128)", M, N, K);
-    VQ_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
-             "gemm_tn256e: operands must be 16-byte aligned with lda/ldw %% 8 == 0");
+    VQ_CHECK(lda % 64 == 0 && ldw % 64 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
+             "gemm_tn256e: operands must be 16-byte aligned with lda/ldw %% 64 == 0");
     static bool attr_set = false;
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256e_kernel<IS_F16, Epi>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + G2_ROWSTAT_BYTES));
         attr_set = true;
     }
     const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
-    hipLaunchKernelGGL((gemm_tn256e_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st,
+    hipLaunchKernelGGL((gemm_tn256e_kernel<IS_F16, Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
+                       G2_LDS_BYTES + (epi_row_in<Epi>::value ? G2_ROWSTAT_BYTES : 0), st,
                        A, lda, W, ldw, K, tiles_n, epi, gemm_order2d());
     VQ_HIP(hipGetLastError());
     return 0;
-    }
 }
 
 template <bool IS_F16, class Epi, bool BUF = true /* false: global_load_lds staging (A/B: 1.5-3.5 % slower, 18 more VGPRs) */>

@@ -309,12 +309,13 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
                 }
             }
+            if ((force == 9 || force == 12) && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
             return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         }
         return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     } else {
-    const bool allow160 = force != 6;
-    if (force == 6) force = 0;
+    const bool allow160 = force != 6 && force != 12;
+    if (force == 6 || force == 12) force = 0;     // 12 = 6 with the two-phase mainloop for the LayerNorm-consuming GEMMs (A/B switch)
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
         return launch_gemm_tn160_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #ifdef VQ_GEMM_EXPERIMENTS
@@ -326,11 +327,11 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, false>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 9 && fits256 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #ifdef VQ_GEMM_EXPERIMENTS
-    if (force == 9) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #else
-    if (force == 9 || force == 10)
+    if (force == 10)
         return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
 #endif
     if (force == 2) return launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
