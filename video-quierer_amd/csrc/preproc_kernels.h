@@ -119,6 +119,121 @@ void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tm
     }
 }
 
+// Horizontal pass, row-block-major form.  Measured on resample_h_kernel with s_memtime stamps (1080p -> 224, 64 frames):
+// of a workgroup's 23-26k cycles, 11-14k go to ISSUING its 48 LDS-DMA requests per wave — the requests queue behind a
+// memory system that serves this pattern (a ~570-byte piece of each of 64 rows 5,760 bytes apart, per workgroup, with
+// the pieces of one row spread over workgroups on different XCDs) at ~2 TB/s — and 6.8k to the multiply-adds.  Here a
+// workgroup keeps its RSH_ROWS rows and walks `spw` consecutive column segments left to right: what it asks for next
+// continues where its last request ended (the halo lines of a segment boundary are in its XCD's L2), a row's span is
+// ONE wave-wide request of aligned 16-byte loads held in registers, and the next segment's pixels and weights are in
+// flight while the current one is multiplied.  Same LDS image, lane = row compute loop and tile store as above.
+template <bool DWORD_STORE>
+__global__ __launch_bounds__(RS_THREADS)
+void resample_hx_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
+                        const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                        int h, int w, int row_first, int rows_needed, int col_first, int out_cols,
+                        int oc, int pitch_dw, int tile_pitch, int spw /* segments per workgroup */) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    uint8_t* tile = (uint8_t*)(lds32 + RSH_ROWS * pitch_dw);        // [64][tile_pitch] bytes
+    int* kl = (int*)(tile + RSH_ROWS * tile_pitch);                  // [oc][ksize] weights of the current segment's columns
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int img = blockIdx.z, r0 = blockIdx.y * RSH_ROWS;
+    const int nseg = (out_cols + oc - 1) / oc;
+    const int s_begin = blockIdx.x * spw, s_end = min(nseg, s_begin + spw);
+    const size_t pitch = (size_t)w * 3;
+    const uint8_t* frame = src + ((size_t)img * h + row_first) * pitch;
+
+    uint4 v[RSH_ROWS / 4];
+    int kw[4];                                                       // host: oc * ksize <= 4 * RS_THREADS
+    auto issue = [&](int sg) {                                       // segment sg: pixels of rows w, w+4, ... and its weights -> registers
+        const int xo0 = sg * oc, ncol = min(oc, out_cols - xo0), xx0 = col_first + xo0;
+        const int sx0 = bounds[2 * xx0];
+        const int span_bytes = (bounds[2 * (xx0 + ncol - 1)] + bounds[2 * (xx0 + ncol - 1) + 1] - sx0) * 3;
+#pragma unroll
+        for (int i = 0; i < RSH_ROWS / 4; ++i) {
+            const int row = min(r0 + wave + 4 * i, rows_needed - 1);     // rows past the end repeat the last one, never stored
+            const uint8_t* g = frame + (size_t)row * pitch + (size_t)sx0 * 3;
+            const int a = (int)((uintptr_t)g & 15);
+            v[i] = uint4{0u, 0u, 0u, 0u};
+            // an aligned 16-byte chunk that holds a valid byte never leaves that byte's page
+            if (lane < ((a + span_bytes + 15) >> 4)) v[i] = *(const uint4*)(g - a + 16 * (size_t)lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = (int)threadIdx.x + RS_THREADS * u;
+            kw[u] = idx < ncol * ksize ? kk[(size_t)xx0 * ksize + idx] : 0;
+        }
+    };
+    if (s_begin < s_end) issue(s_begin);
+    for (int sg = s_begin; sg < s_end; ++sg) {
+        const int xo0 = sg * oc, ncol = min(oc, out_cols - xo0), xx0 = col_first + xo0;
+        const int sx0 = bounds[2 * xx0];
+        if (4 * lane < pitch_dw - 3) {
+#pragma unroll
+            for (int i = 0; i < RSH_ROWS / 4; ++i) {
+                uint32_t* d = lds32 + (wave + 4 * i) * pitch_dw + 4 * lane;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = (int)threadIdx.x + RS_THREADS * u;
+            if (idx < oc * ksize) kl[idx] = kw[u];
+        }
+        __syncthreads();                                             // segment staged; every wave is done with the previous tile
+        if (sg + 1 < s_end) issue(sg + 1);
+
+        // ---- compute: lane = row ----
+        const int my_row = min(r0 + lane, rows_needed - 1);
+        const int a = (int)((uintptr_t)(frame + (size_t)my_row * pitch + (size_t)sx0 * 3) & 15);
+        const uint32_t* rowp = lds32 + lane * pitch_dw;
+        for (int c = wave; c < ncol; c += 4) {
+            const int xx = xx0 + c;
+            const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+            const int4* k = (const int4*)(kl + c * ksize);          // wave-uniform address: an LDS broadcast read
+            const int off = a + (xmin - sx0) * 3;
+            int di = off >> 2;
+            const int sh = off & 3;
+            int s0 = 1 << (RS_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            uint32_t d0 = rowp[di];
+            const int nchunk = (cnt + 3) >> 2;
+            for (int q = 0; q < nchunk; ++q) {
+                const uint32_t d1 = rowp[di + 1], d2 = rowp[di + 2], d3 = rowp[di + 3];
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                const uint32_t e1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                const int4 kq = k[q];
+                const int k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;
+                s0 += __mul24((int)(e0 & 255), k0);         s1 += __mul24((int)((e0 >> 8) & 255), k0);  s2 += __mul24((int)((e0 >> 16) & 255), k0);
+                s0 += __mul24((int)(e0 >> 24), k1);         s1 += __mul24((int)(e1 & 255), k1);         s2 += __mul24((int)((e1 >> 8) & 255), k1);
+                s0 += __mul24((int)((e1 >> 16) & 255), k2); s1 += __mul24((int)(e1 >> 24), k2);         s2 += __mul24((int)(e2 & 255), k2);
+                s0 += __mul24((int)((e2 >> 8) & 255), k3);  s1 += __mul24((int)((e2 >> 16) & 255), k3); s2 += __mul24((int)(e2 >> 24), k3);
+                d0 = d3;
+                di += 3;
+            }
+            uint8_t* o = tile + lane * tile_pitch + c * 3;
+            o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+        }
+        __syncthreads();
+
+        // ---- store the 64 x ncol tile, row-contiguous ----
+        const int rows = min(RSH_ROWS, rows_needed - r0);
+        uint8_t* out0 = tmp + (((size_t)img * rows_needed + r0) * out_cols + xo0) * 3;
+        const size_t out_pitch = (size_t)out_cols * 3;
+        if constexpr (DWORD_STORE) {
+            const int nd = (ncol * 3) >> 2;                          // <= 24 dwords: half a wave per row
+            const int j = lane & 31;
+            for (int r = wave * 2 + (lane >> 5); r < rows; r += 8)
+                if (j < nd) *(uint32_t*)(out0 + r * out_pitch + 4 * j) = *(const uint32_t*)(tile + r * tile_pitch + 4 * j);
+        } else {
+            const int nb = ncol * 3;
+            for (int r = wave; r < rows; r += 4)
+                for (int j = lane; j < nb; j += 64) out0[r * out_pitch + j] = tile[r * tile_pitch + j];
+        }
+    }
+}
+
 // Vertical pass (ImagingResampleVertical_8bpc).  A thread produces VEC consecutive bytes of one output row: 16 when
 // rows are 16-byte aligned (one wide load per tap, all taps independent: the pass is latency-bound on its ~11 taps),
 // else 4 or 1.  tmp [n][rows_in][row_bytes], dst [n][out_rows][row_bytes] for output rows [row_first, row_first +

@@ -4,6 +4,8 @@
 #include "preproc_kernels.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -209,13 +211,28 @@ int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int f
     };
     int oc = 32, pitch_dw = 0, tile_pitch = 0;
     size_t lds = 0;
-    for (;;) {
-        pitch_dw = (span_max(oc) * 3 + 24 + 3) / 4 | 1;       // + realignment and zero-weight over-read slack; odd
-        tile_pitch = (oc * 3 + 3) / 4 * 4;
-        if (((tile_pitch / 4) & 1) == 0) tile_pitch += 4;
-        lds = (size_t)RSH_ROWS * pitch_dw * 4 + (size_t)RSH_ROWS * tile_pitch + (size_t)oc * r->ch.ksize * 4;
-        if (lds <= 48 * 1024 || oc == 1) break;
-        oc = oc > 4 ? oc - 4 : oc - 1;
+    // the row-block-major kernel (resample_hx_kernel) needs a staged row to be one wave-wide request of 16-byte loads
+    // (<= 1 KiB with its alignment slack) and a segment's weights to fit four registers per thread
+    static const bool no_hx = []() { const char* e = getenv("VQ_AMD_RSH"); return e && !strcmp(e, "seg"); }();      // A/B switch
+    bool hx = !no_hx;
+    for (int pass = 0; pass < 2; ++pass) {
+        oc = 32;
+        const int slack = hx ? 48 : 24;                      // hx: 15 bytes of alignment instead of 3
+        for (;;) {
+            pitch_dw = (span_max(oc) * 3 + slack + 3) / 4 | 1;    // + realignment and zero-weight over-read slack; odd
+            tile_pitch = (oc * 3 + 3) / 4 * 4;
+            if (((tile_pitch / 4) & 1) == 0) tile_pitch += 4;
+            lds = (size_t)RSH_ROWS * pitch_dw * 4 + (size_t)RSH_ROWS * tile_pitch + (size_t)oc * r->ch.ksize * 4;
+            // LDS per workgroup: 40 KB = four workgroups per CU for the row-block-major kernel (measured 32 / 40 / 48 / 64 KB:
+            // 0.184 / 0.161 / 0.174 / 0.184 ms per 64 1080p frames), 48 KB for the segment-major one; $VQ_AMD_RSH_LDS_KB overrides
+            static const int lds_kb = []() { const char* e = getenv("VQ_AMD_RSH_LDS_KB"); return e ? atoi(e) : 0; }();
+            const size_t lds_cap = (size_t)(lds_kb > 0 ? lds_kb : hx ? 40 : 48) * 1024;
+            const bool fits = lds <= lds_cap && (!hx || (pitch_dw * 4 <= 1024 && oc * r->ch.ksize <= 4 * RS_THREADS));
+            if (fits || oc == 1) break;
+            oc = oc > 4 ? oc - 4 : oc - 1;
+        }
+        if (!hx || (pitch_dw * 4 <= 1024 && oc * r->ch.ksize <= 4 * RS_THREADS && lds <= 96 * 1024)) break;
+        hx = false;                                          // a single output column already spans more than a request: segment-major kernel
     }
     VQ_CHECK(lds <= 150 * 1024, "vq_resampler: a %d -> %d pixel row needs %zu bytes of LDS per workgroup", w, out_w, lds);
     const bool dword_store = (crop_w % 4 == 0) && (oc % 4 == 0);
@@ -223,8 +240,24 @@ int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int f
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute((const void*)resample_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         VQ_HIP(hipFuncSetAttribute((const void*)resample_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        VQ_HIP(hipFuncSetAttribute((const void*)resample_hx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VQ_HIP(hipFuncSetAttribute((const void*)resample_hx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
+    if (hx) {
+        // segments per workgroup: walk as many as leaves ~4+ rounds of workgroups on the chip
+        const int nseg = cdiv(crop_w, oc), yblocks = cdiv(rows_needed, RSH_ROWS);
+        static const int spw_env = []() { const char* e = getenv("VQ_AMD_RSH_SPW"); return e ? atoi(e) : 0; }();
+        int xsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, cdiv((int64_t)4 * 768, (int64_t)yblocks * n)));
+        int spw = spw_env > 0 ? std::min(spw_env, nseg) : cdiv(nseg, xsplit);
+        const dim3 xgrid(cdiv(nseg, spw), yblocks, n);
+        if (dword_store)
+            hipLaunchKernelGGL(resample_hx_kernel<true>, xgrid, dim3(RS_THREADS), lds, r->stream, d_src, (uint8_t*)r->tmp.p,
+                               r->d_bh, r->d_kh, r->ch.ksize, h, w, row_first, rows_needed, crop_left, crop_w, oc, pitch_dw, tile_pitch, spw);
+        else
+            hipLaunchKernelGGL(resample_hx_kernel<false>, xgrid, dim3(RS_THREADS), lds, r->stream, d_src, (uint8_t*)r->tmp.p,
+                               r->d_bh, r->d_kh, r->ch.ksize, h, w, row_first, rows_needed, crop_left, crop_w, oc, pitch_dw, tile_pitch, spw);
+    } else {
     const dim3 hgrid(cdiv(crop_w, oc), cdiv(rows_needed, RSH_ROWS), n);
     if (dword_store)
         hipLaunchKernelGGL(resample_h_kernel<true>, hgrid, dim3(RS_THREADS), lds, r->stream, d_src, (uint8_t*)r->tmp.p,
@@ -232,6 +265,7 @@ int run_device(vq_resampler* r, const uint8_t* d_src, int n, int h, int w, int f
     else
         hipLaunchKernelGGL(resample_h_kernel<false>, hgrid, dim3(RS_THREADS), lds, r->stream, d_src, (uint8_t*)r->tmp.p,
                            r->d_bh, r->d_kh, r->ch.ksize, h, w, row_first, rows_needed, crop_left, crop_w, oc, pitch_dw, tile_pitch);
+    }
     VQ_HIP(hipGetLastError());
     const int row_bytes = crop_w * 3;
     if (row_bytes % 16 == 0 && ((uintptr_t)d_dst & 15) == 0 && ((uintptr_t)r->tmp.p & 15) == 0) {
