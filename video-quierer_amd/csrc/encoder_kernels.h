@@ -148,7 +148,7 @@ template <bool F16, bool GELU>
 struct EpiLnH16 {
     uint16_t* out; int ldo; const float* c2; const float* c1; LnPartials part; int granules; float inv_h, eps;
     const float2* lds = nullptr; int m0 = 0;            // bound per workgroup by the kernel (epi_bind_rowstats)
-    static constexpr bool kLoads = false, kRowIn = true;
+    static constexpr bool kLoads = false, kRowIn = true, kWide = true;
     __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(c2 + n); }
     __device__ __forceinline__ f32x4 aux_at(int n) const { return ld4(c1 + n); }
     __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -176,6 +176,20 @@ struct EpiLnH16 {
             v[i] = y;
         }
         *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
+    }
+    __device__ __forceinline__ void store_ln8(int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, f32x4 a0, f32x4 a1, float2 st) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y0 = st.y * (v0[i] - st.x * a0[i]) + b0[i];
+            float y1 = st.y * (v1[i] - st.x * a1[i]) + b1[i];
+            if constexpr (GELU) {
+                y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * y0));
+                y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * y1));
+            }
+            v0[i] = y0; v1[i] = y1;
+        }
+        const uint2 lo = pack4_h<F16>(v0), hi = pack4_h<F16>(v1);
+        *(uint4*)(out + (size_t)m * ldo + n) = uint4{lo.x, lo.y, hi.x, hi.y};
     }
 };
 

@@ -91,12 +91,18 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
 //   kRowStats  the functor's store_stats() returns the values it stored (the new residual row segment); the epilogue
 //              sums them and their squares over the wave's 64 columns and hands the row's partial (sum, sum of squares)
 //              to put_stats(m, n_wave0, s1, s2) — one partial per (row, 64-column granule), no atomics
+//   kWide      (with kRowIn, 16-bit outputs) a lane owns EIGHT consecutive columns of a row and stores them as one 16-byte
+//              piece, 8 rows per wave instruction: store_ln8(m, n, v0, v1, bias0, bias1, aux0, aux1, stat).  Half as many
+//              store instructions and loop trips as the 4-column form; 8-byte stores per lane are issue-bound
+//              (MI355X_MICROARCH.md, 'attention epilogue store tail': 8x dwordx4 halves 16x dwordx2)
 //   kRowIn     the functor consumes per-row (mean, rstd) prepared by the kernel prologue (row_stat(m), an LDS read) and a
 //              second per-column constant aux_at(n); its store is store_ln(m, n, acc, bias, aux, stat)
 template <class E, class = void> struct epi_row_stats : std::false_type {};
 template <class E> struct epi_row_stats<E, std::void_t<decltype(E::kRowStats)>> : std::bool_constant<E::kRowStats> {};
 template <class E, class = void> struct epi_split_k : std::false_type {};
 template <class E> struct epi_split_k<E, std::void_t<decltype(E::kSplitK)>> : std::bool_constant<E::kSplitK> {};
+template <class E, class = void> struct epi_wide : std::false_type {};
+template <class E> struct epi_wide<E, std::void_t<decltype(E::kWide)>> : std::bool_constant<E::kWide> {};
 template <class E, class = void> struct epi_row_in : std::false_type {};
 template <class E> struct epi_row_in<E, std::void_t<decltype(E::kRowIn)>> : std::bool_constant<E::kRowIn> {};
 
@@ -132,6 +138,35 @@ template <int MI, class Epi>      // wave tile = MI*16 rows x 64 cols; acc[mi][n
 __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI][4], int m_wave0, int n_wave0,
                                               int lane, const Epi& epi) {
     const int frow = lane & 15, fgrp = lane >> 4;
+    if constexpr (epi_wide<Epi>::value) {
+        static_assert(epi_row_in<Epi>::value && !Epi::kLoads, "the 8-column epilogue form is for the LayerNorm-consuming 16-bit outputs");
+        const int wrow = lane >> 3, wcol = lane & 7;
+        const int n8 = n_wave0 + wcol * 8;
+        const f32x4 b0 = epi.bias_at(n8), b1 = epi.bias_at(n8 + 4), a0 = epi.aux_at(n8), a1 = epi.aux_at(n8 + 4);
+#pragma unroll
+        for (int pass = 0; pass < (MI + 1) / 2; ++pass) {
+            const int blocks = (2 * pass + 1 < MI) ? 2 : 1;               // 16-row blocks in this pass (an odd MI ends on one)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (h < blocks) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *(f32x4*)(strip + (h * 16 + frow) * EPI_ROW_BYTES + (ni * 16 + fgrp * 4) * 4) = acc[pass * 2 + h][ni];
+                }
+            // same wave, in-order LDS: the reads below see the writes above
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (it < 2 * blocks) {
+                    const int row = it * 8 + wrow;
+                    const f32x4 v0 = *(const f32x4*)(strip + row * EPI_ROW_BYTES + wcol * 32);
+                    const f32x4 v1 = *(const f32x4*)(strip + row * EPI_ROW_BYTES + wcol * 32 + 16);
+                    const int m = m_wave0 + pass * 32 + row;
+                    epi.store_ln8(m, n8, v0, v1, b0, b1, a0, a1, epi.row_stat(m));
+                }
+            }
+        }
+        return;
+    }
     const int rrow = lane >> 4, rcol = lane & 15;
     const int n = n_wave0 + rcol * 4;
     const f32x4 bias = epi.bias_at(n);

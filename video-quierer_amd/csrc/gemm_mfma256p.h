@@ -25,6 +25,7 @@
 #include "gemm_mfma160.h"
 #include "gemm_mfma256w4.h"
 #include "gemm_mfma256d.h"
+#include "gemm_mfma128x256.h"
 #include "gemm_mfma256f.h"
 
 namespace vq {
@@ -296,6 +297,11 @@ static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one 
 template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
+    // 12: 128x256 tiles, two workgroups per CU, wherever the 256x256 kernel would run (13: on every shape that tiles)
+    if ((force == 12 || force == 13) && M % G12_BM == 0 && N % G12_BN == 0 && K % (2 * G12_SUB_K) == 0 && K >= 4 * G12_SUB_K &&
+        (force == 13 || (int64_t)(M / G12_BM) * (N / G12_BN) >= 256))
+        return launch_gemm_tn128x256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 12 || force == 13) force = 6;
     if constexpr (epi_row_in<Epi>::value) {
         // epilogues that consume per-row LayerNorm statistics need the kernels with the row-stat prologue
         const bool fits = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
@@ -309,13 +315,13 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
                 }
             }
-            if ((force == 9 || force == 12) && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+            if (force == 9 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
             return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         }
         return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     } else {
-    const bool allow160 = force != 6 && force != 12;
-    if (force == 6 || force == 12) force = 0;     // 12 = 6 with the two-phase mainloop for the LayerNorm-consuming GEMMs (A/B switch)
+    const bool allow160 = force != 6;
+    if (force == 6) force = 0;
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
         return launch_gemm_tn160_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #ifdef VQ_GEMM_EXPERIMENTS
