@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Where a tower GEMM workgroup's time goes: prologue / K loop / epilogue cycles of gemm_tn256d_kernel, sampled inside
+the real encoder pass.  Needs the diagnostic build: `make -C video-quierer_amd/csrc STAMPS=1` in a scratch copy of the tree,
+then VQ_AMD_LIB=<that libvq_amd.so> STREAMS=1|3 python scripts/gemm_tower_stamps.py 2>&1 | grep STAMP  (DESIGN.md §4)."""
 import os, sys, ctypes, collections, re, subprocess
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

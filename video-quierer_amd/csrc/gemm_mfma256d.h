@@ -40,6 +40,14 @@
 
 namespace vq {
 
+#ifdef VQ_GEMM_TOWER_STAMPS      // `make STAMPS=1`: diagnostic build for scripts/gemm_tower_stamps.py, never the product library
+__device__ unsigned long long g_dbg_stamps[4096 * 8];
+__device__ unsigned int g_dbg_count;
+#define VQ_TOWER_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define VQ_TOWER_STAMP(v)
+#endif
+
 constexpr int G2D_STAMPS = 512;                    // per wave, CLOCK == 2 diagnostic builds
 constexpr int G2_ROWSTAT_BYTES = G2_BM * 8;      // (mean, rstd) per tile row behind the two K-tile buffers (kRowIn epilogues)
 
@@ -50,6 +58,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
                         const uint16_t* __restrict__ W, int ldw,
                         int K, int tiles_n, Epi epi, int order2d,
                         unsigned long long* __restrict__ clock_out = nullptr /* CLOCK builds: per-workgroup {d memtime, d memrealtime} around the K loop */) {
+    VQ_TOWER_STAMP(ts0);
     typedef mfma_op<IS_F16> op;
     typedef typename op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,6 +250,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     unsigned long long c0 = 0, r0 = 0;
     if constexpr (CLOCK == 1) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
+    VQ_TOWER_STAMP(ts1);
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; kt += 2) {
         tile(kt, 0);
@@ -249,6 +259,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     if (wr == 0) barrier();               // every wave executes the same number of barriers
     barrier();                            // both groups past their last fragment reads before LDS is reused
 #undef VQ_VMCNT
+    VQ_TOWER_STAMP(ts2);
 
     if constexpr (CLOCK == 1) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -261,6 +272,18 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     }
 
     wave_epilogue<8>(smem + wave * EPI_WAVE_BYTES, acc, m0 + wr * 128, n0 + wc * 64, lane, epi_wg);
+#ifdef VQ_GEMM_TOWER_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VQ_TOWER_STAMP(ts3);
+    if (CLOCK == 0 && lane == 0 && wave == 5 && (blockIdx.x % 37) == 5) {      // a sample of workgroups: {K, tiles_n, epilogue tag, cycles x3, grid, id}
+        const unsigned int sl = atomicAdd(&g_dbg_count, 1u);
+        if (sl < 4096) {
+            unsigned long long* d = g_dbg_stamps + sl * 8;
+            d[0] = K; d[1] = tiles_n; d[2] = sizeof(Epi) * 4 + (epi_row_in<Epi>::value ? 1 : 0) + (Epi::kLoads ? 2 : 0);
+            d[3] = ts1 - ts0; d[4] = ts2 - ts1; d[5] = ts3 - ts2; d[6] = gridDim.x; d[7] = blockIdx.x;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -931,3 +931,22 @@ int vq_encoder_debug_read(vq_encoder* e, const char* name, int rows, float* out)
 }
 
 }  // extern "C"
+
+#ifdef VQ_GEMM_TOWER_STAMPS
+// `make STAMPS=1` only: prints and clears the workgroup stamps gemm_tn256d_kernel collected (scripts/gemm_tower_stamps.py)
+extern "C" int vq_debug_dump_gemm_stamps(void) {
+    unsigned int n = 0;
+    static unsigned long long h[4096 * 8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(vq::g_dbg_count), 4);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vq::g_dbg_stamps), sizeof(h));
+    if (n > 4096) n = 4096;
+    for (unsigned i = 0; i < n; ++i) {
+        const unsigned long long* d = h + i * 8;
+        fprintf(stderr, "STAMP K %llu tn %llu epi %llu prologue %llu loop %llu epilogue %llu grid %llu wg %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+    }
+    const unsigned int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vq::g_dbg_count), &z, 4);
+    return (int)n;
+}
+#endif
