@@ -120,12 +120,19 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
                     acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
-    // fold quadrant (hm, hn) of row tile t into the running top-2 and clear it
-    auto fold = [&](int hm, int hn, int t) __attribute__((always_inline)) {
-        const bool ragged = n0 + (int64_t)(t + 1) * 256 > n_valid;     // wave-uniform
+    // fold quadrant (hm, hn) of row tile t into the running top-2 and clear it.  Four vector instructions per score (mask the
+    // index bits in, v_med3_f32 for the second key, a raw v_max_f32 for the first — fmaxf, and med3(first, key, +inf) which the compiler turns
+    // back into it, cost an extra canonicalising v_max per call in IEEE mode) plus the clear.  The row mask of a ragged last tile is a separate copy of the
+    // loop behind a wave-uniform branch: written as `if (ragged && row >= n_valid)` the compiler if-converted it into a 64-bit
+    // add, a 64-bit compare and two selects PER SCORE on every tile (11 instructions per score; the fold was a quarter of the
+    // kernel).
+    auto fold_body = [&](auto ragged_tag, int hm, int hn, int t) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         float2 p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[i] = mm[(hm * 4 + i) * 64];
+        const int row_lane = t * 256 + wc * 64 + 4 * fgrp;              // + ni*16 + r: the row inside the range
+        const int rows_left = (int)min((int64_t)SCAN2_RANGE, n_valid - n0);   // RAGGED only
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -134,15 +141,20 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
                 for (int r = 0; r < 4; ++r) {
                     const int mi = hm * 4 + i, ni = hn * 2 + j;
                     float v = acc[mi][ni][r];
-                    if (ragged && n0 + t * 256 + wc * 64 + ni * 16 + 4 * fgrp + r >= n_valid) v = MASKED;
+                    if constexpr (RAGGED) { if (row_lane + ni * 16 + r >= rows_left) v = MASKED; }
                     const uint32_t kb = (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)(t * 16 + ni * 4 + r);
                     const float kf = __builtin_bit_cast(float, kb);
                     p[i].y = __builtin_amdgcn_fmed3f(p[i].x, p[i].y, kf);
-                    p[i].x = fmaxf(p[i].x, kf);
+                    asm("v_max_f32 %0, %1, %2" : "=v"(p[i].x) : "v"(p[i].x), "v"(kf));      // raw: no canonicalising pre-max
                     acc[mi][ni][r] = 0.f;
                 }
             mm[(hm * 4 + i) * 64] = p[i];
         }
+    };
+    auto fold = [&](int hm, int hn, int t) __attribute__((always_inline)) {
+        const bool ragged = n0 + (int64_t)(t + 1) * 256 > n_valid;     // wave-uniform; true only in the matrix's last range
+        if (__builtin_expect(ragged, 0)) fold_body(std::true_type{}, hm, hn, t);
+        else                             fold_body(std::false_type{}, hm, hn, t);
     };
     auto barrier = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
@@ -159,17 +171,23 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         const bool next = kt + 1 < total, next2 = kt + 2 < total;
         const int kk1 = kk + 1 == nk ? 0 : kk + 1, t1 = kk + 1 == nk ? t + 1 : t;          // K-tile kt + 1
         const int kk2 = kk1 + 1 == nk ? 0 : kk1 + 1, t2 = kk1 + 1 == nk ? t1 + 1 : t1;     // K-tile kt + 2
+        // Where the fold runs (s_memtime stamps): in the READ half of a phase it sits beside the partner wave's
+        // MFMA cluster, which holds the SIMD's vector issue for half of every 16 cycles — a quadrant's 96 vector instructions
+        // took ~1,000 cycles there plus ~340 waiting for the running keys, and a row tile cost 42.5k cycles against 30.5k with no
+        // fold at all.  In the wave's own MFMA half the partner is reading, not multiplying, and the vector pipe is free once
+        // the 16 MFMAs are issued.  Two clusters have registers to spare (the second W sub-block is dead in phases 4 and 1):
+        // quadrants (0,0) (0,1) are folded behind the MFMAs of phase 4 of a row tile's last K-tile, (1,1) (1,0) behind those
+        // of phase 1 of the next K-tile — each before its accumulators are written again.
         // phase 1: quadrant (0,0)
-        if (fold_prev) fold(1, 0, t - 1);
         load_a(buf, 0); load_w(buf, 0);
         if (next) { stage_w(bufi ^ 1, 1, t1, kk1); VQ_VMCNT(8); }
         else      { VQ_VMCNT(2); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         mfma_quadrant(0, 0);
+        if (fold_prev) { fold(1, 1, t - 1); fold(1, 0, t - 1); }
         barrier();
         // phase 2: quadrant (0,1)
-        if (last) fold(0, 0, t);
         load_w(buf, 1);
         if (next) { stage_a(bufi ^ 1, 1, kk1); VQ_VMCNT(8); }
         else      { VQ_VMCNT(0); }
@@ -178,7 +196,6 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         mfma_quadrant(0, 1);
         barrier();
         // phase 3: quadrant (1,1)
-        if (last) fold(0, 1, t);
         load_a(buf, 1);
         if (next2) stage_a(bufi, 0, kk2);
         barrier();
@@ -186,11 +203,11 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         mfma_quadrant(1, 1);
         barrier();
         // phase 4: quadrant (1,0): no fragment reads
-        if (last) fold(1, 1, t);
         if (next2)     { stage_w(bufi, 0, t2, kk2); VQ_VMCNT(8); }
         else if (next) { VQ_VMCNT(4); }
         barrier();
         mfma_quadrant(1, 0);
+        if (last) { fold(0, 0, t); fold(0, 1, t); }
         barrier();
     };
 
@@ -208,7 +225,7 @@ void scan4_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         tile(kt + 1, 1, kk + 1 == nk, false, t, kk);
         if (++kk == nk) { kk = 0; ++t; }
     }
-    fold(1, 0, 7);
+    fold(1, 1, 7); fold(1, 0, 7);
     if (wr == 0) barrier();               // every wave executes the same number of barriers
 #undef VQ_VMCNT
 
