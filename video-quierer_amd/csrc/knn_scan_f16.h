@@ -462,16 +462,21 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
 #pragma unroll
     for (int i = 0; i < RV_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
     float dropped = NEG;
+    // Insertion by compare-and-swap down the sorted list, as SELECTS: written with `if (v > kv[i]) swap` the compiler built an
+    // exec-mask branch per step (~70 instructions per offer, and a wave runs the insertion whenever any of its lanes inserts);
+    // raw v_max for the floor (fmaxf costs a canonicalising pre-max per operand in IEEE mode; the keys are never NaN).
+    auto raw_max = [](float a, float b) __attribute__((always_inline)) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto offer = [&](float v, int src) __attribute__((always_inline)) {
         if (v > kv[RV_KEEP - 1]) {
-            dropped = fmaxf(dropped, kv[RV_KEEP - 1]);
 #pragma unroll
-            for (int i = 0; i < RV_KEEP; ++i) {            // insertion by compare-and-swap down the list
-                if (v > kv[i]) { const float tv = kv[i]; const int ts = ksrc[i]; kv[i] = v; ksrc[i] = src; v = tv; src = ts; }
+            for (int i = 0; i < RV_KEEP; ++i) {
+                const bool gt = v > kv[i];
+                const float hi = gt ? v : kv[i], lo = gt ? kv[i] : v;
+                const int shi = gt ? src : ksrc[i], slo = gt ? ksrc[i] : src;
+                kv[i] = hi; ksrc[i] = shi; v = lo; src = slo;
             }
-        } else {
-            dropped = fmaxf(dropped, v);
         }
+        dropped = raw_max(dropped, v);                 // what fell off the list: the old last key, or v itself
     };
     // 8 independent 8-byte loads in flight per thread (a one-load-per-iteration loop was latency-bound:
     // 488 dependent round trips per thread made this kernel 1.8 ms for 10k queries)
@@ -681,16 +686,18 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
 #pragma unroll
     for (int i = 0; i < RS_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
     float dropped = NEG;
-    auto offer = [&](float v, int src) __attribute__((always_inline)) {
+    auto raw_max = [](float a, float b) __attribute__((always_inline)) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto offer = [&](float v, int src) __attribute__((always_inline)) {          // as in rescore_verify_kernel
         if (v > kv[RS_KEEP - 1]) {
-            dropped = fmaxf(dropped, kv[RS_KEEP - 1]);
 #pragma unroll
             for (int i = 0; i < RS_KEEP; ++i) {
-                if (v > kv[i]) { const float tv = kv[i]; const int ts = ksrc[i]; kv[i] = v; ksrc[i] = src; v = tv; src = ts; }
+                const bool gt = v > kv[i];
+                const float hi = gt ? v : kv[i], lo = gt ? kv[i] : v;
+                const int shi = gt ? src : ksrc[i], slo = gt ? ksrc[i] : src;
+                kv[i] = hi; ksrc[i] = shi; v = lo; src = slo;
             }
-        } else {
-            dropped = fmaxf(dropped, v);
         }
+        dropped = raw_max(dropped, v);
     };
     constexpr int PF = 8;
     int64_t s = tid;
