@@ -345,8 +345,7 @@ __device__ __forceinline__ void emit_xh_and_partials(const float4 (&v)[NV], uint
         *(uint2*)(xh_row + (i * 64 + lane) * 4) = pack4_h<F16>(f32x4{v[i].x, v[i].y, v[i].z, v[i].w});
         float s1 = (v[i].x + v[i].y) + (v[i].z + v[i].w);
         float s2 = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         if ((lane & 15) == 0) part.ps[(size_t)(i * 4 + (lane >> 4)) * part.stride + row] = float2{s1, s2};
     }
 }

@@ -114,8 +114,7 @@ __device__ __forceinline__ void epi_emit(const Epi& epi, int m, int n, int n_wav
         const f32x4 r = epi.store_stats(m, n, v, bias, loaded);
         float s1 = (r[0] + r[1]) + (r[2] + r[3]);
         float s2 = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }     // the 16 lanes of a row: fixed order
+        s1 = row16_sum(s1); s2 = row16_sum(s2);                  // the 16 lanes of a row: fixed order (vq_common.h)
         if (rcol == 0) epi.put_stats(m, n_wave0, s1, s2);
     } else {
         epi.store(m, n, v, bias, loaded);

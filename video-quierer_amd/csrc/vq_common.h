@@ -74,4 +74,16 @@ __host__ __device__ inline float key_dist(uint64_t k) {
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Sum over the 16 lanes of a DPP row, the total in every lane: v_add_f32 with a DPP-permuted source (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute_b32 round trips through the LDS crossbar
+// (what __shfl_xor compiles to: a residual-GEMM workgroup issued 256 of them per wave and waited on each).  Every step adds
+// the same operand pairs as the xor butterfly 1, 2, 4, 8, so the result is bit-identical to it.
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+
 }  // namespace vq
