@@ -17,7 +17,7 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-GEMM_KERNELS = [1, 2, 5, 8, 9, 11, 13]  # 13 = 128x256 tiles, 4 waves, 3-slot ring, two workgroups per CU; 9 = two phases of 32 MFMAs per K-tile (half the barriers), buffer_load..lds staging; 8 stages with buffer_load..lds, 11 = 8 with global_load_lds staging; 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave, 10 register-double-buffered ring: `make EXPERIMENTS=1` builds only)
+GEMM_KERNELS = [1, 2, 5, 8, 9, 11, 13, 16]  # 16 = deep-prefetch 256x256 with several tiles per workgroup (next tile's first K-tile lands under the epilogue); 13 = 128x256 tiles, 4 waves, 3-slot ring, two workgroups per CU; 9 = two phases of 32 MFMAs per K-tile (half the barriers), buffer_load..lds staging; 8 stages with buffer_load..lds, 11 = 8 with global_load_lds staging; 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave, 10 register-double-buffered ring: `make EXPERIMENTS=1` builds only)
 
 
 @pytest.mark.parametrize("kernel", GEMM_KERNELS)

@@ -133,15 +133,21 @@ __device__ __forceinline__ Epi epi_bind_rowstats(const Epi& epi, float2* lds_sta
     return e;
 }
 
-template <int MI, class Epi>      // wave tile = MI*16 rows x 64 cols; acc[mi][ni] = C[16mi + lane&15][16ni + 4(lane>>4) ..+3]
+struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_loads()` runs once, right behind the epilogue's first global loads (per-column constants, first residual rows):
+// the multi-tile kernel issues the NEXT tile's LDS-DMA there — vmcnt retires in order, so a load issued behind that DMA
+// would wait for it to land, which is the very latency the DMA is issued early to hide.
+template <int MI, class Epi, class Hook = EpiNoHook>      // wave tile = MI*16 rows x 64 cols; acc[mi][ni] = C[16mi + lane&15][16ni + 4(lane>>4) ..+3]
 __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI][4], int m_wave0, int n_wave0,
-                                              int lane, const Epi& epi) {
+                                              int lane, const Epi& epi, const Hook& after_loads = Hook()) {
     const int frow = lane & 15, fgrp = lane >> 4;
     if constexpr (epi_wide<Epi>::value) {
         static_assert(epi_row_in<Epi>::value && !Epi::kLoads, "the 8-column epilogue form is for the LayerNorm-consuming 16-bit outputs");
         const int wrow = lane >> 3, wcol = lane & 7;
         const int n8 = n_wave0 + wcol * 8;
         const f32x4 b0 = epi.bias_at(n8), b1 = epi.bias_at(n8 + 4), a0 = epi.aux_at(n8), a1 = epi.aux_at(n8 + 4);
+        after_loads();
 #pragma unroll
         for (int pass = 0; pass < (MI + 1) / 2; ++pass) {
             const int blocks = (2 * pass + 1 < MI) ? 2 : 1;               // 16-row blocks in this pass (an odd MI ends on one)
@@ -180,6 +186,7 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
 #pragma unroll
         for (int it = 0; it < (FULL > 0 ? 8 : 4); ++it) loaded[0][it] = epi.load(m_wave0 + it * 4 + rrow, n);
     }
+    after_loads();
 #pragma unroll
     for (int pass = 0; pass < FULL; ++pass) {
         if constexpr (Epi::kLoads) {

@@ -287,6 +287,206 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Multi-tile form of gemm_tn256d_kernel: a workgroup computes `tpw` consecutive tiles of ONE tile row (tiles_n % tpw == 0)
+// and the first K-tile of tile i+1 lands WHILE tile i's epilogue runs.  Stamps: a K = 768 workgroup spends
+// ~5k of its ~50k cycles waiting for its first operands, and a 256x256 workgroup owns its CU, so nothing computes meanwhile;
+// here only the first tile of a workgroup pays that.  LDS: buffer 0 = [0, 64K) takes the next tile's K-tile 0 during the
+// epilogue, whose per-wave transposition strips therefore live in [64K, 64K + 8 x 8704) (buffer 1 and the 5.5 KiB behind
+// it), the LayerNorm row statistics behind them (the rows are those of the whole tile row: computed once).
+//   after the K loop      every fragment read has retired (final barrier)      -> stage K-tile 0 of the next tile into buffer 0
+//   epilogue              strips in buffer 1 (its last reads were the last K-tile's)
+//   barrier               every wave is done with its strip                    -> stage A0, W0 of K-tile 1 into buffer 1
+//   s_waitcnt vmcnt(4)    K-tile 0 (and the epilogue's stores) retired, the two new units stay in flight; barrier; K loop
+// Same mainloop, schedule and hazards as gemm_tn256d_kernel.  lda / ldw % 64 == 0 (four lane-offset registers).
+constexpr int G2M_STRIP_OFF = G2_BUF;                                        // strips start at buffer 1
+constexpr int G2M_ROWSTAT_OFF = G2_BUF + 8 * EPI_WAVE_BYTES;                 // 135,168
+constexpr int G2M_LDS_BYTES = G2M_ROWSTAT_OFF + G2_ROWSTAT_BYTES;            // 137,216
+
+template <bool IS_F16, class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void gemm_tn256dm_kernel(const uint16_t* __restrict__ A, int lda,
+                         const uint16_t* __restrict__ W, int ldw,
+                         int K, int tiles_n, Epi epi, int tpw) {
+    typedef mfma_op<IS_F16> op;
+    typedef typename op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int groups_n = tiles_n / tpw;                  // workgroups per tile row
+    const int tm = wg / groups_n, tn0 = (wg - tm * groups_n) * tpw;
+    const int m0 = tm * G2_BM;
+
+    // staging: piece 2w of unit 0 per operand (+ the same ^ 64 for piece 2w+1); unit / piece rows and K offset are scalar
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int arow_w = (wave >> 2) * 128 + (wave & 3) * 16, wrow_w = (wave >> 1) * 64 + (wave & 1) * 16;
+    const int ar = arow_w + srow, wrw = wrow_w + srow;
+    const int a_v0 = (ar * lda + (sslot ^ ((ar >> 1) & 7)) * 8) * 2, a_v1 = a_v0 ^ 64;
+    const int w_v0 = (wrw * ldw + (sslot ^ ((wrw >> 1) & 7)) * 8) * 2, w_v1 = w_v0 ^ 64;
+    const int a_dst0 = arow_w * 128, w_dst0 = 2 * G2_HALF + wrow_w * 128;
+    const int a_row8 = 8 * lda * 2, w_row8 = 8 * ldw * 2;
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+    int w_tile = 0;                                      // byte offset of the current tile's first W row (scalar)
+
+    auto stage_a = [&](int buf, int hm, int kt) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + a_dst0 + hm * (64 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(kt * (G2_BK * 2) + hm * 8 * a_row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base), 16, a_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + 1024), 16, a_v1, soff + a_row8, 0, 0);
+    };
+    auto stage_w_at = [&](int buf, int hn, int kt, int wt) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + w_dst0 + hn * (32 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(wt + kt * (G2_BK * 2) + hn * 4 * w_row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + w_row8, 0, 0);
+    };
+    auto stage_w = [&](int buf, int hn, int kt) __attribute__((always_inline)) { stage_w_at(buf, hn, kt, w_tile); };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;
+
+    f32x4 acc[8][4];
+    frag af[4][2], wf[2][2][2];
+    const int nk = K / G2_BK;
+
+    auto load_a = [&](const char* buf, int hm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf, int hn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[hn][j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
+    };
+    auto mfma_quadrant = [&](int hm, int hn) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    auto tile = [&](int kt, int bufi) __attribute__((always_inline)) {       // one K-tile: as in gemm_tn256d_kernel
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+        load_a(buf, 0); load_w(buf, 0);
+        if (next) { stage_w(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }
+        else      { VQ_VMCNT(2); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 0);
+        barrier();
+        load_w(buf, 1);
+        if (next) { stage_a(bufi ^ 1, 1, kt + 1); VQ_VMCNT(8); }
+        else      { VQ_VMCNT(0); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 1);
+        barrier();
+        load_a(buf, 1);
+        if (next2) stage_a(bufi, 0, kt + 2);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 1);
+        barrier();
+        if (next2)     { stage_w(bufi, 0, kt + 2); VQ_VMCNT(8); }
+        else if (next) { VQ_VMCNT(4); }
+        barrier();
+        mfma_quadrant(1, 0);
+        barrier();
+    };
+
+    // first tile: the whole of K-tile 0 and A0, W0 of K-tile 1; row statistics of the tile row while they are in flight
+    w_tile = __builtin_amdgcn_readfirstlane(tn0 * G2_BN * ldw * 2);
+    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
+    if (nk > 1) { stage_a(1, 0, 1); stage_w(1, 0, 1); }
+    const Epi epi_wg = epi_bind_rowstats<G2_BM>(epi, (float2*)(smem + G2M_ROWSTAT_OFF), m0, tid, G2_THREADS);
+    if (nk > 1) { VQ_VMCNT(8); }
+    else        { VQ_VMCNT(4); }
+    barrier();
+
+    for (int it = 0; it < tpw; ++it) {
+        const int n0 = (tn0 + it) * G2_BN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
+        for (int kt = 0; kt < nk; kt += 2) {
+            tile(kt, 0);
+            tile(kt + 1, 1);
+        }
+        if (wr == 0) barrier();               // every wave executes the same number of barriers
+        barrier();                            // both groups past their last fragment reads
+
+        const bool more = it + 1 < tpw;
+        const int w_next = __builtin_amdgcn_readfirstlane((tn0 + it + 1) * G2_BN * ldw * 2);
+        // the next tile's K-tile 0 -> buffer 0, under this tile's epilogue, behind the epilogue's first loads
+        auto stage_next = [&]() __attribute__((always_inline)) {
+            if (more) { stage_a(0, 0, 0); stage_w_at(0, 0, 0, w_next); stage_w_at(0, 1, 0, w_next); stage_a(0, 1, 0); }
+        };
+        // the row part of the epilogue's addresses is the same for every tile of the workgroup: left alone the compiler hoists
+        // ~20 registers of it across the K loop (and spills them); an opaque move makes it recompute them per tile
+        int m_wave = m0 + wr * 128, lane_e = lane;
+        asm volatile("" : "+v"(m_wave), "+v"(lane_e));
+        wave_epilogue<8>(smem + G2M_STRIP_OFF + wave * EPI_WAVE_BYTES, acc, m_wave, n0 + wc * 64, lane_e, epi_wg, stage_next);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            barrier();                         // every wave is done with its strip: buffer 1 may be refilled
+            w_tile = w_next;
+            if (nk > 1) { stage_a(1, 0, 1); stage_w(1, 0, 1); VQ_VMCNT(4); }
+            else        { VQ_VMCNT(0); }
+            barrier();
+        }
+    }
+#undef VQ_VMCNT
+}
+
+template <bool IS_F16, class Epi>
+static int launch_gemm_tn256dm(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                               int M, int N, int K, const Epi& epi, int tpw) {
+    VQ_CHECK(M > 0 && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0 && tpw >= 1 && (N / G2_BN) % tpw == 0,
+             "gemm_tn256dm: shape M=%d N=%d K=%d / %d tiles per workgroup is not tile-aligned (256/256/128)", M, N, K, tpw);
+    VQ_CHECK(lda % 64 == 0 && ldw % 64 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && (int64_t)N * ldw * 2 < ((int64_t)1 << 31),
+             "gemm_tn256dm: operands must be 16-byte aligned with lda/ldw %% 64 == 0 and W below 2 GiB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256dm_kernel<IS_F16, Epi>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2M_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_m = M / G2_BM, tiles_n = N / G2_BN;
+    hipLaunchKernelGGL((gemm_tn256dm_kernel<IS_F16, Epi>), dim3(tiles_m * (tiles_n / tpw)), dim3(G2_THREADS), G2M_LDS_BYTES, st,
+                       A, lda, W, ldw, K, tiles_n, epi, tpw);
+    VQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Two-phase variant: the same staging units and LDS image, but a K-tile is TWO phases of 32 MFMAs instead of four
 // of 16 — half the barriers (4 per K-tile) and half the points where the first MFMA waits for its fragments:
 //

@@ -288,6 +288,12 @@ static int launch_gemm_tn256_best(hipStream_t st, const uint16_t* A, int lda, co
                            : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
 
+static inline bool gemm_use_multi() {          // $VQ_AMD_GEMM_MULTI=0: one tile per workgroup everywhere
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_MULTI"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v != 0;
+}
+
 static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one launch per GEMM
     static int v = -1;
     if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_TAIL"); v = (e && atoi(e) == 0) ? 0 : 1; }
@@ -316,11 +322,17 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                 }
             }
             if (force == 9 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+            // Three tiles of a tile row per workgroup where that still leaves >= 192 workgroups (fc1 at batch 256): the second
+            // and third tile's first operands land under the previous epilogue (fc1 -3.5 % with one batch in flight, +0.5 % frames/s
+            // with three; qkv would drop to 150 workgroups and lose 29 %).  Concurrent handles only: a lone batch keeps the
+            // tail-split dispatch below.  $VQ_AMD_GEMM_MULTI=0 switches it off, VQ_AMD_GEMM=15 forces it everywhere.
+            if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= 192) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0)
+                return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
             return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         }
         return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     } else {
-    const bool allow160 = force != 6;
+    const bool allow160 = force != 6 && force != 14 && force != 15;
     if (force == 6) force = 0;
     if (force == 5 || (force == 0 && allow160 && gemm_use160() && prefer_tn160(M, N, K)))
         return launch_gemm_tn160_ring<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
@@ -334,6 +346,11 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, false>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 9 && fits256 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+    if (force == 15 && fits256 && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128)
+        return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
+    if (force == 16 && fits256 && lda % 64 == 0 && ldw % 64 == 0)          // tests: the multi-tile kernel on any shape that tiles
+        return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, (N / G2_BN) % 3 == 0 ? 3 : (N / G2_BN) % 2 == 0 ? 2 : 1);
+    if (force == 14 || force == 15 || force == 16) force = 0;
 #ifdef VQ_GEMM_EXPERIMENTS
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #else
