@@ -416,6 +416,26 @@ constexpr int RV_C = 32;          // candidates re-scored exactly
 constexpr int RV_RESCAN_MAX = 4;  // streams re-scored per query before giving up
 constexpr int RV_POOL = RV_C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;   // exact-scored rows per query
 
+// The same chain with the row streamed in batches of eight 16-byte loads (a row straight from HBM: with one load per step a
+// thread paid a full memory round trip per 16 bytes — stamps: 306k of a re-score workgroup's 815k cycles).  dim % 32 == 0.
+__device__ __forceinline__ float exact_dot_chain_pf(const float* __restrict__ row, const float* __restrict__ q, int dim) {
+    double acc = 0.0;
+    for (int i = 0; i < dim; i += 32) {
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *(const float4*)(row + i + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 b = *(const float4*)(q + i + 4 * u);
+            acc += (double)a[u].x * (double)b.x;
+            acc += (double)a[u].y * (double)b.y;
+            acc += (double)a[u].z * (double)b.z;
+            acc += (double)a[u].w * (double)b.w;
+        }
+    }
+    return (float)acc;
+}
+
 __device__ __forceinline__ float exact_dot_chain(const float* __restrict__ row, const float* __restrict__ q, int dim) {
     double acc = 0.0;
     for (int i = 0; i < dim; i += 4) {
@@ -450,6 +470,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     __shared__ int resc_n[RV_QPW];
     __shared__ int state[RV_QPW];
     __shared__ float qn2[RV_QPW][RV_SHARES];                   // partial |q|^2 (the bound scales with |q|)
+    __shared__ float dk_s[RV_QPW];                             // k-th smallest exact distance among the candidates
 
     const int tid = threadIdx.x;
     const int ql = tid % RV_QPW, share = tid / RV_QPW;
@@ -480,17 +501,32 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     };
     // 8 independent 8-byte loads in flight per thread (a one-load-per-iteration loop was latency-bound:
     // 488 dependent round trips per thread made this kernel 1.8 ms for 10k queries)
+    // batches of eight 8-byte loads, the next batch in flight while the current one is offered (one batch at a time waited a
+    // full memory round trip per batch: 194k cycles for 32 batches)
     constexpr int PF = 8;
     int64_t s = share;
-    for (; s + (PF - 1) * RV_SHARES < streams; s += PF * RV_SHARES) {
-        uint2 two[PF];
+    uint2 two[PF], nxt[PF];
+    const bool any_full = s + (PF - 1) * RV_SHARES < streams;
+    if (any_full) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + batch_key_index(s + u * RV_SHARES, q, streams));   // a wave: 8 adjacent 128-byte blocks
+    }
+    for (; s + (PF - 1) * RV_SHARES < streams; s += PF * RV_SHARES) {
+        const int64_t sn = s + PF * RV_SHARES;
+        const bool more = sn + (PF - 1) * RV_SHARES < streams;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) nxt[u] = *(const uint2*)(keys + batch_key_index(sn + u * RV_SHARES, q, streams));
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int src = (int)((s + u * RV_SHARES) * 2);
             offer(__builtin_bit_cast(float, two[u].x), src);
             offer(__builtin_bit_cast(float, two[u].y), src + 1);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) two[u] = nxt[u];
         }
     }
     for (; s < streams; s += RV_SHARES) {
@@ -536,29 +572,35 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             const uint32_t kb = __builtin_bit_cast(uint32_t, cand_key[ql][c]);
             const int64_t r = layout == 3 ? scan3_row_of(src >> 1, (int)(kb & 127u))
                             : layout == 2 ? scan2_row_of(src >> 1, (int)(kb & 127u)) : scan_row_of(src >> 1, (int)(kb & 127u));
-            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain_pf(rows + (size_t)r * dim, qv, dim); }
         }
         cand_row[ql][c] = row; cand_dist[ql][c] = d;
     }
     __syncthreads();
 
-    // ---- 4. k-th best exact score so far; which bounds are still open? (one thread per query) ----
+    // ---- 4. k-th best exact score so far; which bounds are still open? ----
+    // 4a. the k-th smallest exact distance among the C candidates, selection by counting: thread (query, candidate) — one
+    //     thread per query doing all C^2 comparisons held the workgroup for 215k of its 815k cycles
+    {
+        const int kk = k < RV_C ? k : RV_C;
+        if (tid < RV_QPW) dk_s[tid] = __builtin_inff();
+        __syncthreads();
+        for (int c = share; c < RV_C; c += RV_SHARES) {
+            if (cand_row[ql][c] < 0) continue;
+            const uint64_t ki = dist_key(cand_dist[ql][c], (uint32_t)cand_row[ql][c]);
+            int rank = 0;
+            for (int j = 0; j < RV_C; ++j)
+                rank += cand_row[ql][j] >= 0 && dist_key(cand_dist[ql][j], (uint32_t)cand_row[ql][j]) < ki;
+            if (rank == kk - 1) dk_s[ql] = cand_dist[ql][c];            // keys are distinct (the row is in the key): one writer
+        }
+        __syncthreads();
+    }
     if (tid < RV_QPW && q0 + tid < nq) {
         const int qq = tid;
         const int kk = k < RV_C ? k : RV_C;
-        // k-th smallest exact distance among the C candidates (selection by counting)
-        float dk = __builtin_inff(); int have = 0;
+        int have = 0;
         for (int i = 0; i < RV_C; ++i) have += cand_row[qq][i] >= 0;
-        if (have >= kk) {
-            for (int i = 0; i < RV_C; ++i) {
-                if (cand_row[qq][i] < 0) continue;
-                int rank = 0;
-                for (int j = 0; j < RV_C; ++j)
-                    rank += cand_row[qq][j] >= 0 && dist_key(cand_dist[qq][j], (uint32_t)cand_row[qq][j]) <
-                                                        dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
-                if (rank == kk - 1) dk = cand_dist[qq][i];
-            }
-        }
+        const float dk = have >= kk ? dk_s[qq] : __builtin_inff();
         const float sk = 1.0f - dk;                            // k-th best exact score (−inf if fewer than k rows exist)
         float q2 = 0.f;
         for (int sh = 0; sh < RV_SHARES; ++sh) q2 += qn2[qq][sh];
@@ -598,7 +640,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             const int64_t r = layout == 3 ? scan3_row_of(resc_stream[qq][which], local)
                             : layout == 2 ? scan2_row_of(resc_stream[qq][which], local) : scan_row_of(resc_stream[qq][which], local);
             int row = -1; float d = __builtin_inff();
-            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv2, dim); }
+            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain_pf(rows + (size_t)r * dim, qv2, dim); }
             cand_row[qq][RV_C + i] = row; cand_dist[qq][RV_C + i] = d;
         }
         if (tid == 0) pool_n[qq] = RV_C + nres * SCAN_STREAM_ROWS;
