@@ -713,9 +713,9 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     __shared__ int cand_src[RV_C];
     __shared__ int cand_row[RV_POOL];
     __shared__ float cand_dist[RV_POOL];
-    __shared__ float bound_rest_s, floor_max_s, qnorm2_s, dk_s;
+    __shared__ float bound_rest_s, floor_max_s, qnorm2_s, dk_s, thr_s;
     __shared__ int resc_stream[RV_RESCAN_MAX];
-    __shared__ int resc_n, state, pool_n, have_s;
+    __shared__ int resc_n, state, pool_n, have_s, surv_n;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -776,39 +776,56 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         floor_max_s = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     }
 
-    // ---- 2a. each wave: the best RV_C of its 64*RS_KEEP keys (rank = number of better keys, index breaks ties) ----
+    // ---- 2. the best RV_C of the 256*RS_KEEP kept keys.  Ranking all 1,024 of them (inside each wave, then the survivors) was
+    //         104k of this kernel's 195k cycles (s_memtime stamps).  Instead: T = the RV_C-th largest of the 256 thread MAXIMA
+    //         (every one of the overall best RV_C keys is >= the overall RV_C-th largest key >= T, the maxima being a subset);
+    //         the keys >= T — a few dozen — are collected and only they are ranked. ----
+    if (tid < RV_C) { cand_key[tid] = NEG; cand_src[tid] = -1; }
+    if (tid == 0) { thr_s = NEG; surv_n = 0; bound_rest_s = NEG; }
+    __syncthreads();
     {
-        const int base = wave * 64 * RS_KEEP;
-        float vi[RS_KEEP]; int rank[RS_KEEP];
-#pragma unroll
-        for (int i = 0; i < RS_KEEP; ++i) { vi[i] = kept_v[base + lane * RS_KEEP + i]; rank[i] = 0; }
-        for (int j = 0; j < 64 * RS_KEEP; j += 4) {                       // 16-byte LDS reads, the same address in every lane
-            const float4 vj = *(const float4*)(kept_v + base + j);
-            const float v4[4] = {vj.x, vj.y, vj.z, vj.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < RS_KEEP; ++i)
-                    rank[i] += (v4[u] > vi[i]) || (v4[u] == vi[i] && j + u < lane * RS_KEEP + i);
+        const float mx = kv[0];                                               // the thread's list is sorted, best first
+        int r = 0;
+        for (int j2 = 0; j2 < 256; ++j2) {                                    // same address in every lane: LDS broadcast reads
+            const float vj = kept_v[j2 * RS_KEEP];
+            r += (vj > mx) || (vj == mx && j2 < tid);
         }
+        if (r == RV_C - 1) thr_s = mx;                                        // ranks are a permutation: one writer
+    }
+    __syncthreads();
+    {
+        const float thr = thr_s;
+        float below = NEG;                                                    // best kept key NOT collected
 #pragma unroll
         for (int i = 0; i < RS_KEEP; ++i) {
-            if (rank[i] < RV_C) { sel_v[wave * RV_C + rank[i]] = vi[i]; sel_s[wave * RV_C + rank[i]] = kept_s[base + lane * RS_KEEP + i]; }
-            if (rank[i] == RV_C) wave_floor[wave] = vi[i];
+            if (kv[i] >= thr && ksrc[i] >= 0) {
+                const int pos = atomicAdd(&surv_n, 1);
+                if (pos < 4 * RV_C) { sel_v[pos] = kv[i]; sel_s[pos] = ksrc[i]; }
+            } else {
+                below = fmaxf(below, kv[i]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) below = fmaxf(below, __shfl_xor(below, o));
+        if (lane == 0) wave_floor[wave] = below;
+    }
+    __syncthreads();
+    {
+        const int ns = min(surv_n, 4 * RV_C);                                // more than 128 keys tie at the threshold: flagged in step 4
+        if (tid < ns) {
+            const float vi = sel_v[tid]; const int si = sel_s[tid];
+            int rank = 0;
+            for (int j2 = 0; j2 < ns; ++j2) {
+                const float vj = sel_v[j2];
+                rank += (vj > vi) || (vj == vi && sel_s[j2] < si);            // sources are distinct: ranks are a permutation
+            }
+            if (rank < RV_C) { cand_key[rank] = vi; cand_src[rank] = si; }
+            if (rank == RV_C) bound_rest_s = vi;
         }
     }
     __syncthreads();
-    // ---- 2b. the best RV_C of the 4*RV_C survivors ----
-    if (tid < 4 * RV_C) {
-        const float vi = sel_v[tid];
-        int rank = 0;
-        for (int j = 0; j < 4 * RV_C; ++j) {
-            const float vj = sel_v[j];
-            rank += (vj > vi) || (vj == vi && j < tid);
-        }
-        if (rank < RV_C) { cand_key[rank] = vi; cand_src[rank] = sel_s[tid]; }
-        if (rank == RV_C) bound_rest_s = fmaxf(fmaxf(vi, fmaxf(wave_floor[0], wave_floor[1])), fmaxf(wave_floor[2], wave_floor[3]));
-    }
+    if (tid == 0)       // what was kept but not selected: the (RV_C+1)-th collected key and every key below the threshold
+        bound_rest_s = fmaxf(fmaxf(bound_rest_s, fmaxf(wave_floor[0], wave_floor[1])), fmaxf(wave_floor[2], wave_floor[3]));
     __syncthreads();
 
     // ---- 3. exact re-score of the candidates: the RV_C rows (and the query) are staged into LDS by all 256 threads
@@ -864,7 +881,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         const float sk = 1.0f - dk;
         const float eps = eps_rows * sqrtf(qnorm2_s);          // NaN for a non-finite query: every test fails -> exact fallback
         int st = 0, nres = 0;
-        if (have < kk) st = 2;
+        if (have < kk || surv_n > 4 * RV_C) st = 2;      // (more keys tied at the selection threshold than the list holds)
         else {
             if (!(bound_rest_s + eps < sk)) st = 2;            // a kept key outside the best C could still matter
             if (!(floor_max_s + eps < sk)) st = 2;             // a thread dropped a key that could matter
