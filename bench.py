@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Batches in flight overlap only when their streams sit on different hardware queues; HIP's default pool of 4 is shared
+# with torch's and the copy streams (video-quierer_amd/_lib.py).  Read when the HIP runtime starts: set before torch loads.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BATCH = 256
 FLOP_PER_FRAME = 2 * 4_408_811_520          # 8.818 GFLOP / frame (full 50-token forward)
