@@ -489,15 +489,16 @@ def test_fp16_scan_random_matches_oracle_bit_exact(gpu_lib):
 
 
 def test_small_batch_streaming_scan_matches_oracle_bit_exact(gpu_lib):
-    """Batches of <= 64 queries (the reference searches one query at a time, video_search_system.py:297) take the
-    HBM-bound streaming scan (scan3_f16_top2_kernel, 16 queries per pass): same proof, same bit-exact answers."""
+    """Batches of <= 96 queries (the reference searches one query at a time, video_search_system.py:297) take the
+    HBM-bound streaming scan (scan3_f16_top2_kernel, 16 or 32 queries per pass): same proof, same bit-exact answers."""
     rng = np.random.default_rng(41)
     vecs = rng.standard_normal((20001, 512)).astype(np.float32)       # ragged last stream (33 rows)
-    qs = rng.standard_normal((64, 512)).astype(np.float32)
-    for nq, k in ((1, 10), (1, 1), (5, 20), (16, 10), (17, 10), (64, 32)):
+    qs = rng.standard_normal((96, 512)).astype(np.float32)
+    for nq, k in ((1, 10), (1, 1), (5, 20), (16, 10), (17, 10), (32, 10), (33, 5), (64, 32), (96, 10)):   # > 16: two query groups per pass
         st = _scan_vs_oracle(vecs, qs[:nq], k)
         assert k > 20 or st["exact_fallback"] <= 1, (nq, k, st)    # k = 32 = every candidate slot: the proof rarely closes, the fallback answers
     _scan_vs_oracle(vecs[:16400, :256], qs[:3, :256], 5)                # dim 256 instantiation
+    _scan_vs_oracle(vecs[:16400, :256], qs[:21, :256], 5)
     _scan_vs_oracle(vecs[:16400, :128], qs[:3, :128], 5)                # other dims keep the MFMA-tile scan
     # near-duplicate runs: stream rescans and the exact fallback behind the streaming scan
     centers = rng.standard_normal((200, 512)).astype(np.float32)

@@ -44,8 +44,10 @@ namespace vq {
 __device__ unsigned long long g_dbg_stamps[4096 * 8];
 __device__ unsigned int g_dbg_count;
 #define VQ_TOWER_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define VQ_TOWER_REALTIME(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime()     /* constant 100 MHz */
 #else
 #define VQ_TOWER_STAMP(v)
+#define VQ_TOWER_REALTIME(v)
 #endif
 
 constexpr int G2D_STAMPS = 512;                    // per wave, CLOCK == 2 diagnostic builds
@@ -251,6 +253,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     if constexpr (CLOCK == 1) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     VQ_TOWER_STAMP(ts1);
+    VQ_TOWER_REALTIME(tr1);
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; kt += 2) {
         tile(kt, 0);
@@ -260,6 +263,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     barrier();                            // both groups past their last fragment reads before LDS is reused
 #undef VQ_VMCNT
     VQ_TOWER_STAMP(ts2);
+    VQ_TOWER_REALTIME(tr2);
 
     if constexpr (CLOCK == 1) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -275,13 +279,11 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
 #ifdef VQ_GEMM_TOWER_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VQ_TOWER_STAMP(ts3);
-    if (CLOCK == 0 && lane == 0 && wave == 5 && (blockIdx.x % 37) == 5) {      // a sample of workgroups: {K, tiles_n, epilogue tag, cycles x3, grid, id}
-        const unsigned int sl = atomicAdd(&g_dbg_count, 1u);
-        if (sl < 4096) {
-            unsigned long long* d = g_dbg_stamps + sl * 8;
-            d[0] = K; d[1] = tiles_n; d[2] = sizeof(Epi) * 4 + (epi_row_in<Epi>::value ? 1 : 0) + (Epi::kLoads ? 2 : 0);
-            d[3] = ts1 - ts0; d[4] = ts2 - ts1; d[5] = ts3 - ts2; d[6] = gridDim.x; d[7] = blockIdx.x;
-        }
+    if (CLOCK == 0 && lane == 0 && wave == 5 && (blockIdx.x % 37) == 5) {      // a sample of workgroups: {K, tiles_n, epilogue tag, cycles x3, K-loop wall ticks, id}
+        const unsigned int sl = atomicAdd(&g_dbg_count, 1u) % 4096u;       // a ring: the dump holds the LAST 4096 samples
+        unsigned long long* d = g_dbg_stamps + sl * 8;
+        d[0] = K; d[1] = tiles_n; d[2] = sizeof(Epi) * 4 + (epi_row_in<Epi>::value ? 1 : 0) + (Epi::kLoads ? 2 : 0);
+        d[3] = ts1 - ts0; d[4] = ts2 - ts1; d[5] = ts3 - ts2; d[6] = tr2 - tr1 /* 10 ns ticks over the K loop */; d[7] = blockIdx.x;
     }
 #endif
 }

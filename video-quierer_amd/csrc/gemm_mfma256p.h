@@ -288,6 +288,12 @@ static int launch_gemm_tn256_best(hipStream_t st, const uint16_t* A, int lda, co
                            : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
 
+static inline int gemm_multi_min_wgs() {        // $VQ_AMD_GEMM_MULTI_MIN: fewest workgroups a three-tile launch may leave (default 192)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_MULTI_MIN"); v = e ? atoi(e) : 192; }
+    return v;
+}
+
 static inline bool gemm_use_multi() {          // $VQ_AMD_GEMM_MULTI=0: one tile per workgroup everywhere
     static int v = -1;
     if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_MULTI"); v = (e && atoi(e) == 0) ? 0 : 1; }
@@ -326,7 +332,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
             // and third tile's first operands land under the previous epilogue (fc1 -3.5 % with one batch in flight, +0.5 % frames/s
             // with three; qkv would drop to 150 workgroups and lose 29 %).  Concurrent handles only: a lone batch keeps the
             // tail-split dispatch below.  $VQ_AMD_GEMM_MULTI=0 switches it off, VQ_AMD_GEMM=15 forces it everywhere.
-            if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= 192) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0)
+            if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= gemm_multi_min_wgs()) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0)
                 return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
             return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         }

@@ -52,7 +52,7 @@ static inline float scan_eps_unit(int dim) {
 // Key layout of the batch scans: [group of 16 queries][stream][16 queries][2 keys].  A scan lane group writes the
 // 128 bytes of (stream, 16 queries) at once, and the re-score workgroup of a query group walks its streams through
 // CONTIGUOUS memory (stream-major [stream][q_pad] made every one of its reads a 64-128 byte piece of a different
-// 80 KB row: the pass moved 0.67 GB at ~0.7 TB/s).  The streaming scan for <= 64 queries keeps [stream][q_pad].
+// 80 KB row: the pass moved 0.67 GB at ~0.7 TB/s).  The streaming scan for <= SCAN3_MAX_Q queries keeps [stream][q_pad].
 __host__ __device__ inline size_t batch_key_index(int64_t stream, int64_t q, int64_t streams) {
     return (((size_t)(q >> 4) * streams + stream) * 16 + (q & 15)) * 2;
 }

@@ -11,7 +11,13 @@
 //   rows 4g..4g+3 of the block; it folds its 32 scores per stream into a top-2 (score with the 7-bit local row
 //   index in the low mantissa bits, as scan*_f16_top2 do), the four lanes of a query merge their top-2 by
 //   shuffles, and lane g = 0 writes the stream's two keys.  Key layout 3 for rescore_verify_kernel:
-//   row = stream*128 + local.  More than 16 queries: one pass per 16 (blockIdx.y), Q <= 64.
+//   row = stream*128 + local.
+//
+// NQG = 2 keeps TWO groups of 16 queries in registers (128 VGPRs of B fragments at dim 512), so 17..32 queries still read
+// the matrix ONCE (q32 was two passes = 2 GB for 0.365 ms; the MFMA and fold work per 16 KiB block stays far under the
+// HBM time).  To make room the row fragments are single-buffered and refilled in rotation: fragment ks of the NEXT block is
+// requested right after the MFMAs that consumed fragment ks of this one, so 16 loads (16 KiB per wave) stay in flight.
+// More queries: one pass per 16*NQG (blockIdx.y), Q <= SCAN3_MAX_Q.
 #pragma once
 #include "vq_common.h"
 #include "gemm_mfma.h"
@@ -19,14 +25,15 @@
 namespace vq {
 
 constexpr int SCAN3_QB = 16;            // queries per pass
-constexpr int SCAN3_MAX_Q = 64;         // beyond this the 256-query MFMA tile wins
+constexpr int SCAN3_MAX_Q = 96;         // three 32-query passes (0.22 ms each over 1M x 512) still beat one 256-query MFMA tile (0.83 ms)
 
 __host__ __device__ inline int64_t scan3_row_of(int64_t stream, int local) { return stream * 128 + local; }
 
-template <int NKS>                      // dim / 32
+template <int NKS, int NQG>             // dim / 32; groups of 16 queries per pass (1 or 2)
 __global__ __launch_bounds__(256, 2)
 void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, const uint16_t* __restrict__ X16,
-                           int64_t n_valid, int64_t streams, int64_t q_pad, uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+                           int64_t n_valid, int64_t streams, int64_t q_pad /* % (16 NQG) == 0 */,
+                           uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     constexpr int DIM = NKS * 32;
@@ -35,51 +42,65 @@ void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, co
     const int64_t stream = (int64_t)blockIdx.x * 4 + wave;
     if (stream >= streams) return;                         // wave-uniform; no barriers below
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.y * SCAN3_QB;
+    const int q0 = blockIdx.y * SCAN3_QB * NQG;
 
-    frag qf[NKS];
+    frag qf[NQG][NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-        qf[ks] = *(const frag*)(Q16 + (size_t)(q0 + r16) * DIM + ks * 32 + g * 8);
+    for (int qg = 0; qg < NQG; ++qg)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[qg][ks] = *(const frag*)(Q16 + (size_t)(q0 + qg * SCAN3_QB + r16) * DIM + ks * 32 + g * 8);
 
     const uint16_t* xrow = X16 + ((size_t)stream * 128 + r16) * DIM + g * 8;
-    frag xf[2][NKS];
+    frag xf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) xf[0][ks] = *(const frag*)(xrow + ks * 32);
+    for (int ks = 0; ks < NKS; ++ks) xf[ks] = *(const frag*)(xrow + ks * 32);
 
     const float NEG = -__builtin_inff(), MASKED = -3.0e38f;   // finite sentinel: see scan_f16_top2_kernel
-    float m1 = NEG, m2 = NEG;
+    float m1[NQG], m2[NQG];
+#pragma unroll
+    for (int qg = 0; qg < NQG; ++qg) { m1[qg] = NEG; m2[qg] = NEG; }
     const bool ragged = (stream + 1) * 128 > n_valid;      // wave-uniform
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
-        if (rb + 1 < 8) {
+        f32x4 acc[NQG];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) xf[(rb + 1) & 1][ks] = *(const frag*)(xrow + (size_t)(rb + 1) * 16 * DIM + ks * 32);
+        for (int qg = 0; qg < NQG; ++qg) acc[qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int qg = 0; qg < NQG; ++qg) acc[qg] = op::run(xf[ks], qf[qg][ks], acc[qg]);
+            if (rb + 1 < 8) {                                                                            // refill in rotation
+                xf[ks] = *(const frag*)(xrow + (size_t)(rb + 1) * 16 * DIM + ks * 32);
+                __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks the load to its use (one register, vmcnt(0) per MFMA)
+            }
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) acc = op::run(xf[rb & 1][ks], qf[ks], acc);
+        for (int qg = 0; qg < NQG; ++qg)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[r];
-            const int local = rb * 16 + 4 * g + r;
-            if (ragged && stream * 128 + local >= n_valid) v = MASKED;
-            const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)local);
-            m2 = __builtin_amdgcn_fmed3f(m1, m2, kf);
-            m1 = fmaxf(m1, kf);
-        }
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[qg][r];
+                const int local = rb * 16 + 4 * g + r;
+                if (ragged && stream * 128 + local >= n_valid) v = MASKED;
+                const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & ~127u) | (uint32_t)local);
+                m2[qg] = __builtin_amdgcn_fmed3f(m1[qg], m2[qg], kf);
+                m1[qg] = fmaxf(m1[qg], kf);
+            }
     }
     // merge the four row groups of a query (lanes l, l^16, l^32, l^48): top-2 of two sorted pairs
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        const float b1 = __shfl_xor(m1, o), b2 = __shfl_xor(m2, o);
-        const float lo = fminf(m1, b1);
-        m1 = fmaxf(m1, b1);
-        m2 = fmaxf(lo, fmaxf(m2, b2));
+    for (int qg = 0; qg < NQG; ++qg) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float b1 = __shfl_xor(m1[qg], o), b2 = __shfl_xor(m2[qg], o);
+            const float lo = fminf(m1[qg], b1);
+            m1[qg] = fmaxf(m1[qg], b1);
+            m2[qg] = fmaxf(lo, fmaxf(m2[qg], b2));
+        }
+        if (g == 0)
+            *(uint2*)(keys + ((size_t)stream * q_pad + q0 + qg * SCAN3_QB + r16) * 2) =
+                uint2{__builtin_bit_cast(uint32_t, m1[qg]), __builtin_bit_cast(uint32_t, m2[qg])};
     }
-    if (g == 0)
-        *(uint2*)(keys + ((size_t)stream * q_pad + q0 + r16) * 2) =
-            uint2{__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m2)};
 }
 
 }  // namespace vq

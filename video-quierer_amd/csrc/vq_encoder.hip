@@ -943,7 +943,7 @@ extern "C" int vq_debug_dump_gemm_stamps(void) {
     if (n > 4096) n = 4096;
     for (unsigned i = 0; i < n; ++i) {
         const unsigned long long* d = h + i * 8;
-        fprintf(stderr, "STAMP K %llu tn %llu epi %llu prologue %llu loop %llu epilogue %llu grid %llu wg %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        fprintf(stderr, "STAMP K %llu tn %llu epi %llu prologue %llu loop %llu epilogue %llu ticks %llu wg %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
     }
     const unsigned int z = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vq::g_dbg_count), &z, 4);

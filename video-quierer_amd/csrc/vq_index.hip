@@ -51,7 +51,7 @@ struct vq_index {
     bool norm_dirty = false, near_unit = true;
     float row_norm_max = 1.0f;
     int scan_version = 4;          // $VQ_AMD_SCAN: 4 = 256x256 deep-prefetch mainloop (needs dim % 128 == 0), 2 = 256x256 four-phase, 1 = 128x128
-    bool no_small_scan = false;    // $VQ_AMD_SCAN_SMALL=0: batches of <= 64 queries also take the MFMA-tile scan (A/B switch)
+    bool no_small_scan = false;    // $VQ_AMD_SCAN_SMALL=0: batches of <= SCAN3_MAX_Q queries also take the MFMA-tile scan (A/B switch)
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
@@ -169,7 +169,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // streaming scan; the 256-query MFMA tile is for batches
     const bool small = nq <= SCAN3_MAX_Q && (x->dim == 512 || x->dim == 256) && !x->no_small_scan;
     const int ver = small ? 3 : x->scan_version;                       // 3: streaming, 2: 256x256 phased mainloop, 1: 128x128
-    const int QT = ver == 3 ? SCAN3_QB : ver >= 2 ? SCAN2_QT : SCAN_QT;
+    const int nqg3 = nq > SCAN3_QB ? 2 : 1;                            // query groups the streaming scan holds per pass
+    const int QT = ver == 3 ? SCAN3_QB * nqg3 : ver >= 2 ? SCAN2_QT : SCAN_QT;
     const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver >= 2 ? SCAN2_RANGE : SCAN_RANGE;
     const int64_t n_pad = round_up(n, RANGE);
     const int64_t streams = n_pad / SCAN_STREAM_ROWS;
@@ -226,12 +227,9 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             Prof p(x, I_MFMA_SCAN);
             if (ver == 3) {
                 const dim3 grid(cdiv(streams, 4), q_tiles);
-                if (x->dim == 512)
-                    hipLaunchKernelGGL(scan3_f16_top2_kernel<16>, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams,
-                                       q_pad, x->d_keys);
-                else
-                    hipLaunchKernelGGL(scan3_f16_top2_kernel<8>, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams,
-                                       q_pad, x->d_keys);
+                auto scan3 = x->dim == 512 ? (nqg3 == 2 ? scan3_f16_top2_kernel<16, 2> : scan3_f16_top2_kernel<16, 1>)
+                                           : (nqg3 == 2 ? scan3_f16_top2_kernel<8, 2> : scan3_f16_top2_kernel<8, 1>);
+                hipLaunchKernelGGL(scan3, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams, q_pad, x->d_keys);
             } else if (ver == 2 || ver == 4) {
                 const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
                 if (ver == 4)
