@@ -30,6 +30,7 @@ FLOP_PER_FRAME = 2 * 4_408_811_520          # 8.818 GFLOP / fram
 PEAK_BF16 = 2.5e15                          # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_FP16 = 2.5e15
 PEAK_HBM = 8.0e12
+PMC_TRAFFIC_FILES = ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json")   # newest first
 METRIC = "frames/sec CLIP ViT-B/32 encode + queries/sec top-10 over 1M×512 embeds"
 
 
@@ -324,7 +325,7 @@ def main():
         # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
         # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/, gfx950 correction applied there)
         traffic, tsrc = None, None
-        for cand in ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json"):
+        for cand in PMC_TRAFFIC_FILES:
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
@@ -425,11 +426,14 @@ def main():
             scan_ms = sp.get("scan_f16_mfma_top2", {}).get("ms", 0.0)
             if scan_ms > 0:
                 scan_traffic = None
-                try:
-                    with open(os.path.join(ROOT, "profiles", "r02b_pmc_traffic.json")) as f:
-                        scan_traffic = json.load(f)["kernels"].get("scan_f16_mfma_top2", {}).get("hbm_bytes")
-                except OSError:
-                    pass
+                for cand in PMC_TRAFFIC_FILES:
+                    try:
+                        with open(os.path.join(ROOT, "profiles", cand)) as f:
+                            scan_traffic = json.load(f)["kernels"].get("scan_f16_mfma_top2", {}).get("hbm_bytes")
+                        if scan_traffic is not None:
+                            break
+                    except OSError:
+                        pass
                 srch["roofline"]["scan_kernel"] = {"ms": scan_ms, "achieved": 2.0 * nq * n_rows * dimq / (scan_ms * 1e-3) / 1e12,
                                                    "frac": 2.0 * nq * n_rows * dimq / (scan_ms * 1e-3) / PEAK_FP16,
                                                    # bytes from beyond L2 per launch (rocprofv3 PMC, 10k x 1M x 512): the matrix

@@ -500,6 +500,10 @@ def test_small_batch_streaming_scan_matches_oracle_bit_exact(gpu_lib):
     _scan_vs_oracle(vecs[:16400, :256], qs[:3, :256], 5)                # dim 256 instantiation
     _scan_vs_oracle(vecs[:16400, :256], qs[:21, :256], 5)
     _scan_vs_oracle(vecs[:16400, :128], qs[:3, :128], 5)                # other dims keep the MFMA-tile scan
+    wide = rng.standard_normal((16500, 768)).astype(np.float32)         # ViT-L/14's embedding width (configs[4]): one group of 16 per pass
+    wq = rng.standard_normal((20, 768)).astype(np.float32)
+    _scan_vs_oracle(wide, wq[:1], 10)
+    _scan_vs_oracle(wide, wq, 10)
     # near-duplicate runs: stream rescans and the exact fallback behind the streaming scan
     centers = rng.standard_normal((200, 512)).astype(np.float32)
     dup = (np.repeat(centers, 100, axis=0) + 1e-3 * rng.standard_normal((20000, 512))).astype(np.float32)

@@ -86,6 +86,7 @@ void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, co
                 m2[qg] = __builtin_amdgcn_fmed3f(m1[qg], m2[qg], kf);
                 m1[qg] = fmaxf(m1[qg], kf);
             }
+        __builtin_amdgcn_sched_barrier(0);      // the fold stays with its block (deferred folds kept 8 blocks of scores alive: spills)
     }
     // merge the four row groups of a query (lanes l, l^16, l^32, l^48): top-2 of two sorted pairs
 #pragma unroll

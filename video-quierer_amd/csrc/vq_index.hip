@@ -167,9 +167,9 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     const int64_t n = x->size;
     // small batches (the reference's one-query-at-a-time search, video_search_system.py:297) take the HBM-bound
     // streaming scan; the 256-query MFMA tile is for batches
-    const bool small = nq <= SCAN3_MAX_Q && (x->dim == 512 || x->dim == 256) && !x->no_small_scan;
+    const bool small = nq <= SCAN3_MAX_Q && (x->dim == 512 || x->dim == 256 || x->dim == 768) && !x->no_small_scan;
     const int ver = small ? 3 : x->scan_version;                       // 3: streaming, 2: 256x256 phased mainloop, 1: 128x128
-    const int nqg3 = nq > SCAN3_QB ? 2 : 1;                            // query groups the streaming scan holds per pass
+    const int nqg3 = nq > SCAN3_QB && x->dim <= 512 ? 2 : 1;           // query groups the streaming scan holds per pass (768-d: 96 + 96 VGPRs for one)
     const int QT = ver == 3 ? SCAN3_QB * nqg3 : ver >= 2 ? SCAN2_QT : SCAN_QT;
     const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver >= 2 ? SCAN2_RANGE : SCAN_RANGE;
     const int64_t n_pad = round_up(n, RANGE);
@@ -199,7 +199,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         static bool attr3_set = false;
         if (!attr3_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)rescore_verify_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (RV_C * (512 + 4) + 512) * 4));
+                                       (RV_C * (768 + 4) + 768) * 4));
             attr3_set = true;
         }
     }
@@ -227,7 +227,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             Prof p(x, I_MFMA_SCAN);
             if (ver == 3) {
                 const dim3 grid(cdiv(streams, 4), q_tiles);
-                auto scan3 = x->dim == 512 ? (nqg3 == 2 ? scan3_f16_top2_kernel<16, 2> : scan3_f16_top2_kernel<16, 1>)
+                auto scan3 = x->dim == 768 ? scan3_f16_top2_kernel<24, 1>
+                           : x->dim == 512 ? (nqg3 == 2 ? scan3_f16_top2_kernel<16, 2> : scan3_f16_top2_kernel<16, 1>)
                                            : (nqg3 == 2 ? scan3_f16_top2_kernel<8, 2> : scan3_f16_top2_kernel<8, 1>);
                 hipLaunchKernelGGL(scan3, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams, q_pad, x->d_keys);
             } else if (ver == 2 || ver == 4) {
