@@ -52,7 +52,7 @@ static inline float scan_eps_unit(int dim) {
 // Key layout of the batch scans: [group of 16 queries][stream][16 queries][2 keys].  A scan lane group writes the
 // 128 bytes of (stream, 16 queries) at once, and the re-score workgroup of a query group walks its streams through
 // CONTIGUOUS memory (stream-major [stream][q_pad] made every one of its reads a 64-128 byte piece of a different
-// 80 KB row: the pass moved 0.67 GB at ~0.7 TB/s).  The streaming scan for <= SCAN3_MAX_Q queries keeps [stream][q_pad].
+// 80 KB row: the pass moved 0.67 GB at ~0.7 TB/s).  The streaming scan for <= SCAN3_MAX_Q queries writes [q_pad][stream] (knn_scan_small.h).
 __host__ __device__ inline size_t batch_key_index(int64_t stream, int64_t q, int64_t streams) {
     return (((size_t)(q >> 4) * streams + stream) * 16 + (q & 15)) * 2;
 }
@@ -688,14 +688,22 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
 // rescore_verify_kernel walks streams/16 keys per thread (488 dependent steps at 1M rows: 0.26 ms for a single
 // query, more than the HBM-bound scan in front of it); here the 256 threads of a workgroup split one query's
 // streams 256 ways (31 steps at 1M rows).  Same proof, same outcome codes, same exact arithmetic:
-//   1. thread t keeps the best RS_KEEP keys of streams t, t+256, ...; whatever it drops is bounded by `dropped`
-//   2. the best RV_C of the 256*RS_KEEP kept keys: rank counting inside each wave (256 keys -> 32), then over the
-//      4*32 survivors; the best key NOT selected bounds every kept-but-unselected key
-//   3. exact fp64-chain re-score of the RV_C candidates from the fp32 master (one thread per candidate)
+//   1. pass A over the keys: each thread's largest key; T = min over the waves of the wave's 8th largest thread maximum
+//      (>= 32 keys reach T, so the best RV_C do); pass B: the keys >= T are collected (a few dozen), the largest key
+//      below T bounds everything else
+//   2. the collected keys are ranked; the best RV_C become candidates, the next one joins the bound
+//   3. exact fp64-chain re-score of the candidates from the fp32 master (one thread per candidate), the best
+//      max(16, k + 6) first, the others only if their best key could still reach the k-th exact score
 //   4. k-th best exact score s_k; every bound + eps must lie below it; a stream whose 2nd key could still matter
 //      is re-scored in full (<= RV_RESCAN_MAX), its candidates dropped from the pool (no duplicates)
 //   5. exact top-k of the pool by (distance, row): rank counting
-constexpr int RS_KEEP = 4;
+
+#ifdef VQ_GEMM_TOWER_STAMPS      // `make STAMPS=1` diagnostic build only (scripts/rescore_stamps.py): phase boundaries of query 0's workgroup
+__device__ unsigned long long g_rs_stamps[16];
+#define VQ_RS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_rs_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VQ_RS_STAMP(i)
+#endif
 
 __global__ __launch_bounds__(256)
 void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
@@ -703,8 +711,6 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  const float* __restrict__ queries, int nq, int k,
                                  int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
                                  int32_t* __restrict__ flags, float eps_rows) {
-    __shared__ __attribute__((aligned(16))) float kept_v[256 * RS_KEEP];
-    __shared__ int kept_s[256 * RS_KEEP];
     __shared__ float sel_v[4 * RV_C];
     __shared__ int sel_s[4 * RV_C];
     __shared__ float wave_floor[4];
@@ -713,7 +719,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     __shared__ int cand_src[RV_C];
     __shared__ int cand_row[RV_POOL];
     __shared__ float cand_dist[RV_POOL];
-    __shared__ float bound_rest_s, floor_max_s, qnorm2_s, dk_s, thr_s;
+    __shared__ float bound_rest_s, qnorm2_s, dk_s;
     __shared__ int resc_stream[RV_RESCAN_MAX];
     __shared__ int resc_n, state, pool_n, have_s, surv_n;
 
@@ -723,95 +729,82 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     const float NEG = -__builtin_inff();
     const float* qv = queries + (size_t)q * dim;
 
-    // ---- 1. per-thread top RS_KEEP of its streams ----
-    float kv[RS_KEEP]; int ksrc[RS_KEEP];
-#pragma unroll
-    for (int i = 0; i < RS_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
-    float dropped = NEG;
-    auto raw_max = [](float a, float b) __attribute__((always_inline)) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-    auto offer = [&](float v, int src) __attribute__((always_inline)) {          // as in rescore_verify_kernel
-        if (v > kv[RS_KEEP - 1]) {
-#pragma unroll
-            for (int i = 0; i < RS_KEEP; ++i) {
-                const bool gt = v > kv[i];
-                const float hi = gt ? v : kv[i], lo = gt ? kv[i] : v;
-                const int shi = gt ? src : ksrc[i], slo = gt ? ksrc[i] : src;
-                kv[i] = hi; ksrc[i] = shi; v = lo; src = slo;
-            }
-        }
-        dropped = raw_max(dropped, v);
-    };
-    constexpr int PF = 8;
-    int64_t s = tid;
-    for (; s + (PF - 1) * 256 < streams; s += PF * 256) {
+    VQ_RS_STAMP(0);
+    // ---- 1. the best RV_C of the query's 2*streams keys, and a bound on all the others.  The keys (query-major: one contiguous
+    //         run, L2-resident) are read TWICE instead of each thread keeping a sorted short list of its share: pass A takes each
+    //         thread's largest key; T = the smallest, over the four waves, of the wave's 8th largest thread maximum, so at least
+    //         32 keys are >= T and the overall best RV_C are among them; pass B collects the keys >= T (a few dozen) and the
+    //         largest key below T.  (Stamps: the insertion lists cost ~30 instructions per key whenever ANY lane of the wave
+    //         inserted — 23k cycles; ranking the 256 maxima against each other another ~10k.) ----
+    constexpr int PF = 16;
+    const uint2 NONE = uint2{0xFF800000u, 0xFF800000u};      // a missing stream reads as -inf
+    const uint32_t* qkeys = keys + (size_t)q * streams * 2;    // layout 3: query-major
+    // thread -> first stream: by thread id (a wave reads 512 contiguous bytes); on a small index interleaved over the waves,
+    // so that every wave owns at least 8 streams as soon as the keys no longer all fit the collected list
+    const int p0 = streams < 512 ? 4 * lane + wave : tid;
+    float mx = NEG;
+    for (int64_t s = p0; s < streams; s += PF * 256) {
         uint2 two[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + ((size_t)(s + u * 256) * q_pad + q) * 2);
+        for (int u = 0; u < PF; ++u) { const int64_t su = s + u * 256; two[u] = su < streams ? *(const uint2*)(qkeys + su * 2) : NONE; }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int src = (int)((s + u * 256) * 2);
-            offer(__builtin_bit_cast(float, two[u].x), src);
-            offer(__builtin_bit_cast(float, two[u].y), src + 1);
+        for (int u = 0; u < PF; ++u) mx = fmaxf(mx, __builtin_bit_cast(float, two[u].x));      // a stream's 2nd key is never above its 1st
+    }
+    VQ_RS_STAMP(1);
+    {   // the wave's 8th largest maximum: take the wave maximum eight times, retiring one holder each time
+        float cur = mx, t8 = NEG;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            t8 = wave64_max(cur);
+            const unsigned long long holders = __ballot(cur == t8);
+            if (lane == (int)__builtin_ctzll(holders)) cur = NEG;      // (all -inf: lane 0 "retires", nothing changes)
         }
+        if (lane == 0) wave_floor[wave] = t8;
     }
-    for (; s < streams; s += 256) {
-        const uint2 two = *(const uint2*)(keys + ((size_t)s * q_pad + q) * 2);
-        offer(__builtin_bit_cast(float, two.x), (int)(s * 2));
-        offer(__builtin_bit_cast(float, two.y), (int)(s * 2 + 1));
-    }
-#pragma unroll
-    for (int i = 0; i < RS_KEEP; ++i) { kept_v[tid * RS_KEEP + i] = kv[i]; kept_s[tid * RS_KEEP + i] = ksrc[i]; }
-    {   // |q|^2 and the largest dropped key: wave shuffles, then four partials through `red`
+    {   // |q|^2: wave sums, then four partials through `red`
         float s2 = 0.f;
         for (int i = tid; i < dim; i += 256) s2 += qv[i] * qv[i];
-        float dr = dropped;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); dr = fmaxf(dr, __shfl_xor(dr, o)); }
-        if (lane == 0) { red[wave] = s2; red[4 + wave] = dr; }
-        if (tid == 0) { resc_n = 0; state = 0; }
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        if (lane == 0) red[wave] = s2;
     }
-    __syncthreads();
-    if (tid == 0) {
-        qnorm2_s = (red[0] + red[1]) + (red[2] + red[3]);
-        floor_max_s = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-    }
-
-    // ---- 2. the best RV_C of the 256*RS_KEEP kept keys.  Ranking all 1,024 of them (inside each wave, then the survivors) was
-    //         104k of this kernel's 195k cycles (s_memtime stamps).  Instead: T = the RV_C-th largest of the 256 thread MAXIMA
-    //         (every one of the overall best RV_C keys is >= the overall RV_C-th largest key >= T, the maxima being a subset);
-    //         the keys >= T — a few dozen — are collected and only they are ranked. ----
     if (tid < RV_C) { cand_key[tid] = NEG; cand_src[tid] = -1; }
-    if (tid == 0) { thr_s = NEG; surv_n = 0; bound_rest_s = NEG; }
+    if (tid == 0) { resc_n = 0; state = 0; surv_n = 0; bound_rest_s = NEG; }
     __syncthreads();
+    VQ_RS_STAMP(2);
+    const float thr = fminf(fminf(wave_floor[0], wave_floor[1]), fminf(wave_floor[2], wave_floor[3]));
+    if (tid == 0) qnorm2_s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();                                           // wave_floor is rewritten below
     {
-        const float mx = kv[0];                                               // the thread's list is sorted, best first
-        int r = 0;
-        for (int j2 = 0; j2 < 256; ++j2) {                                    // same address in every lane: LDS broadcast reads
-            const float vj = kept_v[j2 * RS_KEEP];
-            r += (vj > mx) || (vj == mx && j2 < tid);
-        }
-        if (r == RV_C - 1) thr_s = mx;                                        // ranks are a permutation: one writer
-    }
-    __syncthreads();
-    {
-        const float thr = thr_s;
-        float below = NEG;                                                    // best kept key NOT collected
+        float below = NEG;                                     // best key NOT collected
+        for (int64_t s = p0; s < streams; s += PF * 256) {
+            uint2 two[PF];
 #pragma unroll
-        for (int i = 0; i < RS_KEEP; ++i) {
-            if (kv[i] >= thr && ksrc[i] >= 0) {
-                const int pos = atomicAdd(&surv_n, 1);
-                if (pos < 4 * RV_C) { sel_v[pos] = kv[i]; sel_s[pos] = ksrc[i]; }
-            } else {
-                below = fmaxf(below, kv[i]);
+            for (int u = 0; u < PF; ++u) { const int64_t su = s + u * 256; two[u] = su < streams ? *(const uint2*)(qkeys + su * 2) : NONE; }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const float v = __builtin_bit_cast(float, w ? two[u].y : two[u].x);
+                    const bool keep = v >= thr && v > NEG;                 // (thr = -inf on a tiny index: every real key)
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {                                                // one LDS atomic per wave and collected group
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&surv_n, __builtin_popcountll(m));
+                        base = __shfl(base, 0);
+                        const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        if (keep && pos < 4 * RV_C) { sel_v[pos] = v; sel_s[pos] = (int)((s + u * 256) * 2) + w; }
+                    }
+                    if (!keep) below = fmaxf(below, v);
+                }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) below = fmaxf(below, __shfl_xor(below, o));
+        below = wave64_max(below);
         if (lane == 0) wave_floor[wave] = below;
     }
     __syncthreads();
     {
-        const int ns = min(surv_n, 4 * RV_C);                                // more than 128 keys tie at the threshold: flagged in step 4
+        const int ns = min(surv_n, 4 * RV_C);                                // more keys than the list holds reach the threshold: flagged in step 4
         if (tid < ns) {
             const float vi = sel_v[tid]; const int si = sel_s[tid];
             int rank = 0;
@@ -824,13 +817,17 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         }
     }
     __syncthreads();
-    if (tid == 0)       // what was kept but not selected: the (RV_C+1)-th collected key and every key below the threshold
+    if (tid == 0)       // what was not selected: the (RV_C+1)-th collected key and every key below the threshold
         bound_rest_s = fmaxf(fmaxf(bound_rest_s, fmaxf(wave_floor[0], wave_floor[1])), fmaxf(wave_floor[2], wave_floor[3]));
     __syncthreads();
 
-    // ---- 3. exact re-score of the candidates: the RV_C rows (and the query) are staged into LDS by all 256 threads
+    VQ_RS_STAMP(3);
+    // ---- 3. exact re-score of the candidates: the rows (and the query) are staged into LDS by all 256 threads
     //         in one round of wide loads — a thread walking its own 2-KiB row straight from HBM pays one exposed
-    //         round trip per 16 bytes — then one thread per candidate runs the fixed-order fp64 chain out of LDS ----
+    //         round trip per 16 bytes — then one thread per candidate runs the fixed-order fp64 chain out of LDS.
+    //         Two passes: a random row of the fp32 master costs an address translation (~1.1k cycles each, served one after the
+    //         other: 32 rows = 35k cycles, stamps), so the best `c1` candidates go first and the others follow only when the
+    //         best key among them could still reach the k-th exact score found so far. ----
     if (tid < RV_C) {
         const int src = cand_src[tid];
         int row = -1;
@@ -840,64 +837,99 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
             if (r < n_valid) row = (int)r;
         }
         cand_row[tid] = row;
+        cand_dist[tid] = __builtin_inff();
     }
-    __syncthreads();
-    {
-        extern __shared__ __attribute__((aligned(16))) float rs_dyn[];        // [RV_C][dim + 4] rows, then [dim] query
-        const int ldr = dim + 4, d4 = dim >> 2;                                // +4 floats: rows on different LDS banks
-        float* qbuf = rs_dyn + RV_C * ldr;
-        for (int i = tid; i < RV_C * d4; i += 256) {
-            const int c = i / d4, j = i - c * d4;
-            const int r = cand_row[c];
-            if (r >= 0) *(float4*)(rs_dyn + c * ldr + 4 * j) = *(const float4*)(rows + (size_t)r * dim + 4 * j);
-        }
-        for (int i = tid; i < d4; i += 256) *(float4*)(qbuf + 4 * i) = *(const float4*)(qv + 4 * i);
-        __syncthreads();
-        if (tid < RV_C) {
-            float d = __builtin_inff();
-            if (cand_row[tid] >= 0) d = 1.0f - exact_dot_chain(rs_dyn + tid * ldr, qbuf, dim);
-            cand_dist[tid] = d;
-        }
-    }
-    __syncthreads();
-
-    // ---- 4. which bounds are still open?  k-th best exact distance by rank counting (one thread per candidate) ----
-    if (tid == 0) { dk_s = __builtin_inff(); have_s = 0; }
-    __syncthreads();
     const int kk = k < RV_C ? k : RV_C;
-    if (tid < RV_C && cand_row[tid] >= 0) {
-        const uint64_t ki = dist_key(cand_dist[tid], (uint32_t)cand_row[tid]);
-        int rank = 0;
+    const int c1 = min(RV_C, max(16, (k + 6 + 7) & ~7));        // first pass: k candidates and a margin, whole groups of 8
+    int limit = c1, my_rank = -1;                                // candidates re-scored; this thread's candidate among them by (distance, row)
+    extern __shared__ __attribute__((aligned(16))) float rs_dyn[];        // [RV_C][dim + 4] rows, then [dim] query
+    const int ldr = dim + 4, d4 = dim >> 2;                                // +4 floats: rows on different LDS banks
+    float* qbuf = rs_dyn + RV_C * ldr;
+    static_assert(RV_C * 8 == 256, "eight threads stage one candidate row");
+    for (int pass = 0; pass < 2; ++pass) {
+        const int lo = pass == 0 ? 0 : c1, hi = pass == 0 ? c1 : RV_C;
+        if (tid == 0) dk_s = __builtin_inff();
+        __syncthreads();                                         // cand_row / the decision of the previous pass visible
+        {   // thread = (candidate c, eighth e): float4 e, e + 8, ... of the row, 16 loads issued before the first LDS store
+            const int c = tid >> 3, e = tid & 7;
+            const int r = c >= lo && c < hi ? cand_row[c] : -1;
+            if (r >= 0) {
+                const float4* src = (const float4*)(rows + (size_t)r * dim);
+                float4* dst = (float4*)(rs_dyn + c * ldr);
+                for (int j0 = e; j0 < d4; j0 += 8 * 16) {
+                    float4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = src[min(j0 + 8 * u, d4 - 1)];      // always loaded (clamped): a conditionally
+#pragma unroll                                                                              // written array goes to scratch
+                    for (int u = 0; u < 16; ++u) if (j0 + 8 * u < d4) dst[j0 + 8 * u] = v[u];
+                }
+            }
+        }
+        if (pass == 0) {
+            VQ_RS_STAMP(4);
+            for (int i = tid; i < d4; i += 256) *(float4*)(qbuf + 4 * i) = *(const float4*)(qv + 4 * i);
+        }
+        __syncthreads();
+        if (pass == 0) VQ_RS_STAMP(5);
+        if (tid >= lo && tid < hi && cand_row[tid] >= 0) cand_dist[tid] = 1.0f - exact_dot_chain(rs_dyn + tid * ldr, qbuf, dim);
+        __syncthreads();
+
+        // ---- 4. k-th best exact distance among the candidates re-scored so far, by rank counting (all in wave 0) ----
+        my_rank = -1;
+        if (tid < hi && cand_row[tid] >= 0) {
+            const uint64_t ki = dist_key(cand_dist[tid], (uint32_t)cand_row[tid]);
+            int rank = 0;
 #pragma unroll 8
-        for (int j = 0; j < RV_C; ++j)
-            rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
-        if (rank == kk - 1) dk_s = cand_dist[tid];
-        atomicAdd(&have_s, 1);
+            for (int j = 0; j < hi; ++j)
+                rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
+            if (rank == kk - 1) dk_s = cand_dist[tid];
+            my_rank = rank;
+        }
+        if (wave == 0) {
+            const int have = __builtin_popcountll(__ballot(my_rank >= 0));
+            if (lane == 0) have_s = have;
+        }
+        __syncthreads();
+        limit = hi;
+        if (hi == RV_C) break;
+        {   // the best key not re-scored yet bounds every candidate behind it (cand_key is sorted): can it still matter?
+            const float dk = have_s >= kk ? dk_s : __builtin_inff();
+            const float nextkey = cand_key[hi];
+            const bool more = nextkey > NEG && !(nextkey + eps_rows * sqrtf(qnorm2_s) < 1.0f - dk);     // same values in every thread
+            __syncthreads();                                     // ... and every thread has read them before pass 1 resets dk_s
+            if (!more) break;
+        }
     }
-    __syncthreads();
-    if (tid == 0) {
+    VQ_RS_STAMP(6);
+    if (wave == 0) {       // the verdict: every lane tests its own candidate, lane 0 collects (was one thread walking all RV_C)
         const int have = have_s;
         const float dk = have >= kk ? dk_s : __builtin_inff();
         const float sk = 1.0f - dk;
         const float eps = eps_rows * sqrtf(qnorm2_s);          // NaN for a non-finite query: every test fails -> exact fallback
-        int st = 0, nres = 0;
-        if (have < kk || surv_n > 4 * RV_C) st = 2;      // (more keys tied at the selection threshold than the list holds)
-        else {
-            if (!(bound_rest_s + eps < sk)) st = 2;            // a kept key outside the best C could still matter
-            if (!(floor_max_s + eps < sk)) st = 2;             // a thread dropped a key that could matter
-            if (st == 0) {
-                for (int c = 0; c < RV_C; ++c) {
-                    if ((cand_src[c] & 1) && cand_key[c] + eps >= sk) {      // the stream's 2nd key: its unseen rows are bounded only by it
+        // a stream's 2nd key: its unseen rows are bounded only by it (candidates not re-scored lie below sk - eps: never set)
+        const bool second = tid < limit && (cand_src[tid] & 1) && cand_key[tid] + eps >= sk;
+        unsigned long long need = __ballot(second);
+        if (tid >= limit && tid < RV_C) cand_row[tid] = -1;    // not re-scored: not part of the pool
+        if (lane == 0) {
+            int st = 0, nres = 0;
+            if (have < kk || surv_n > 4 * RV_C) st = 2;      // (more keys tied at the selection threshold than the list holds)
+            else {
+                if (!(bound_rest_s + eps < sk)) st = 2;            // a key outside the best C could still matter
+                if (st == 0) {
+                    while (need) {                                   // ascending candidate order, as the serial walk took them
+                        const int c = __builtin_ctzll(need);
+                        need &= need - 1;
                         if (nres < RV_RESCAN_MAX) resc_stream[nres++] = cand_src[c] >> 1; else st = 2;
                     }
+                    if (st == 0 && nres > 0) st = 1;
                 }
-                if (st == 0 && nres > 0) st = 1;
             }
+            state = st; resc_n = st == 1 ? nres : 0;
         }
-        state = st; resc_n = st == 1 ? nres : 0;
     }
     __syncthreads();
 
+    VQ_RS_STAMP(7);
     // ---- 5. stream rescans (all 128 rows, exactly); candidates of a rescanned stream leave the pool ----
     const int nres = resc_n;
     if (nres > 0) {
@@ -915,8 +947,15 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     if (tid == 0) pool_n = RV_C + nres * SCAN_STREAM_ROWS;
     __syncthreads();
 
+    VQ_RS_STAMP(8);
     // ---- 6. exact top-k of the pool: rank by (distance, row); rows are distinct, so ranks are a permutation ----
-    {
+    if (nres == 0) {       // no rescans: the pool is the candidate list and step 4's ranks are the answer
+        const int have = have_s;
+        if (tid == 0) flags[q] = state;
+        for (int j = tid; j < k; j += 256)
+            if (j >= have) { out_ids[(size_t)q * k + j] = -1; out_dist[(size_t)q * k + j] = __builtin_inff(); }
+        if (my_rank >= 0 && my_rank < k) { out_ids[(size_t)q * k + my_rank] = cand_row[tid]; out_dist[(size_t)q * k + my_rank] = cand_dist[tid]; }
+    } else {
         const int pn = pool_n;
         if (tid == 0) flags[q] = state;
         for (int j = tid; j < k; j += 256) { out_ids[(size_t)q * k + j] = -1; out_dist[(size_t)q * k + j] = __builtin_inff(); }
@@ -930,6 +969,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
             if (rank < k) { out_ids[(size_t)q * k + rank] = cand_row[i]; out_dist[(size_t)q * k + rank] = cand_dist[i]; }
         }
     }
+    VQ_RS_STAMP(9);
 }
 
 }  // namespace vq

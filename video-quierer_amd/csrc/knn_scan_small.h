@@ -10,8 +10,10 @@
 //   live in registers for the whole kernel (dim/32 fragments).  D[row][query]: lane (q = l&15, g = l>>4) gets
 //   rows 4g..4g+3 of the block; it folds its 32 scores per stream into a top-2 (score with the 7-bit local row
 //   index in the low mantissa bits, as scan*_f16_top2 do), the four lanes of a query merge their top-2 by
-//   shuffles, and lane g = 0 writes the stream's two keys.  Key layout 3 for rescore_verify_kernel:
-//   row = stream*128 + local.
+//   shuffles, and lane g = 0 writes the stream's two keys.  Key layout 3 (rescore_verify_small_kernel): QUERY-major
+//   [q_pad][streams][2], row = stream*128 + local — the single query's re-score pass reads its 62 KB of keys as one
+//   contiguous run (stream-major, they lay 128 B apart over 1 MB: sixteen 64-KB translations and 64 lines per wave load,
+//   20k cycles until the first 16 keys per thread had landed).
 //
 // NQG = 2 keeps TWO groups of 16 queries in registers (128 VGPRs of B fragments at dim 512), so 17..32 queries still read
 // the matrix ONCE (q32 was two passes = 2 GB for 0.365 ms; the MFMA and fold work per 16 KiB block stays far under the
@@ -33,7 +35,7 @@ template <int NKS, int NQG>             // dim / 32; groups of 16 queries per pa
 __global__ __launch_bounds__(256, 2)
 void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, const uint16_t* __restrict__ X16,
                            int64_t n_valid, int64_t streams, int64_t q_pad /* % (16 NQG) == 0 */,
-                           uint32_t* __restrict__ keys /*[streams][q_pad][2]*/) {
+                           uint32_t* __restrict__ keys /*[q_pad][streams][2]*/) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     constexpr int DIM = NKS * 32;
@@ -99,7 +101,7 @@ void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, co
             m2[qg] = fmaxf(lo, fmaxf(m2[qg], b2));
         }
         if (g == 0)
-            *(uint2*)(keys + ((size_t)stream * q_pad + q0 + qg * SCAN3_QB + r16) * 2) =
+            *(uint2*)(keys + ((size_t)(q0 + qg * SCAN3_QB + r16) * streams + stream) * 2) =
                 uint2{__builtin_bit_cast(uint32_t, m1[qg]), __builtin_bit_cast(uint32_t, m2[qg])};
     }
 }

@@ -501,3 +501,17 @@ int vq_index_last_search_stats(vq_index* x, int64_t* stats) {
 }
 
 }  // extern "C"
+
+#ifdef VQ_GEMM_TOWER_STAMPS
+// `make STAMPS=1` only: the phase boundaries rescore_verify_small_kernel's workgroup 0 stamped in its last launch (scripts/rescore_stamps.py)
+extern "C" int vq_debug_dump_rescore_stamps(void) {
+    unsigned long long h[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vq::g_rs_stamps), sizeof(h));
+    static const char* names[9] = {"keys pass A: thread maxima", "wave 8th largest, |q|^2, barrier", "keys pass B: collect, rank", "first-pass rows -> LDS", "query -> LDS, barrier",
+                                   "fp64 chains, k-th distance (+ 2nd pass)", "verdict", "rescans", "top-k out"};
+    for (int i = 0; i < 9; ++i) fprintf(stderr, "RS_STAMP %-32s %8llu cycles\n", names[i], h[i + 1] - h[i]);
+    fprintf(stderr, "RS_STAMP %-32s %8llu cycles\n", "total", h[9] - h[0]);
+    return 0;
+}
+#endif
