@@ -511,6 +511,24 @@ def test_small_batch_streaming_scan_matches_oracle_bit_exact(gpu_lib):
     print("streaming scan, clustered data:", st)
 
 
+def test_small_batch_rescore_across_index_sizes(gpu_lib):
+    """The single-query re-score pass picks its candidates through a per-wave threshold: the geometry changes with the number of
+    128-row streams (< 35: every key is collected; < 512: streams interleaved over the waves; beyond: by thread id) and the
+    candidates are re-scored in two passes (the best max(16, k+6) first).  Bit-exact against the oracle on every side of those."""
+    rng = np.random.default_rng(43)
+    vecs = rng.standard_normal((70000, 512)).astype(np.float32)
+    qs = rng.standard_normal((33, 512)).astype(np.float32)
+    for n in (1, 9, 100, 4300, 4500, 33000, 65500, 65700, 70000):      # 1 .. 547 streams
+        for nq, k in ((1, 10), (7, 1), (33, 32), (2, 20)):
+            st = _scan_vs_oracle(vecs[:n], qs[:nq], k)
+            # (two keys per 128-row stream: an index of fewer than 64 k rows cannot offer k candidates, the exact fallback answers)
+            assert k > 20 or n < 64 * k or st["exact_fallback"] <= 1, (n, nq, k, st)
+    # exact ties across streams (every row appears 3 times): equal keys at the selection threshold and at the k-th place
+    tied = np.concatenate([vecs[:3000]] * 3)
+    _scan_vs_oracle(tied, qs[:3], 10)
+    _scan_vs_oracle(tied, vecs[:2] + 0, 6)                                # the query IS a stored row: distance ~0 three times
+
+
 def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
     rng = np.random.default_rng(32)
     # video-like: runs of 40 near-duplicate neighbours (adjacent rows), 1e-3 apart
