@@ -31,6 +31,23 @@ PEAK_BF16 = 2.5e15                          # dense bf16 MFMA, MI355X_MICROARCH.
 PEAK_FP16 = 2.5e15
 PEAK_HBM = 8.0e12
 PMC_TRAFFIC_FILES = ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json")   # newest first
+
+
+def pmc_bytes(*classes):
+    """HBM-side bytes per launch of the named kernel classes (summed), from the newest committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, scripts/pmc_traffic.py; gfx950 correction applied there) — not measurable in-process."""
+    for cand in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                kernels = json.load(f)["kernels"]
+        except OSError:
+            continue
+        vals = [kernels.get(c, {}).get("hbm_bytes") for c in classes]
+        if all(v is not None for v in vals):
+            return sum(vals), f"profiles/{cand} (rocprofv3 PMC)"
+    return None, None
+
+
 METRIC = "frames/sec CLIP ViT-B/32 encode + queries/sec top-10 over 1M×512 embeds"
 
 
@@ -411,7 +428,9 @@ def main():
             lat[f"q{nq_small}"] = {"ms": 1e3 * t, "queries_per_s": nq_small / t,
                                     "roofline": {"bound": "hbm", "achieved": matrix_bytes / t / 1e9, "peak": PEAK_HBM / 1e9,
                                                  "unit": "GB/s", "frac": matrix_bytes / t / PEAK_HBM,
-                                                 "bytes_per_pass": matrix_bytes}}
+                                                 "bytes_per_pass": matrix_bytes,
+                                                 # PMC bytes of ONE pass of the streaming scan (<= 32 queries: one pass)
+                                                 "traffic": pmc_bytes("scan_f16_stream_top2")[0] if dimq == 512 and n_rows == 1_000_000 else None}}
         srch["latency"] = lat
         if rank == 0:
             for nq_small in (1, 32):                                 # where a small batch's time goes (device side)
@@ -512,7 +531,9 @@ def main():
         prep = {"value": pn / pms * 1e3, "unit": "frames/s", "workload": f"{pn} device-resident {ph}x{pw} BGR uint8 frames -> "
                 "224x224, PIL bilinear (transforms.Resize((224,224))), bit-identical to Pillow", "ms_per_batch": pms,
                 "roofline": {"bound": "hbm", "achieved": alg_bytes / pms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                             "frac": alg_bytes / pms / 1e6 / 8000.0, "traffic": None}}
+                             "frac": alg_bytes / pms / 1e6 / 8000.0,
+                             # both passes of the resize, PMC (64 x 1080p): the horizontal pass over-fetches segment halos
+                             "traffic": pmc_bytes("resample_h", "resample_v")[0]}}
         if not args.no_cpu_baseline:
             try:
                 import PIL
