@@ -777,25 +777,45 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     __syncthreads();                                           // wave_floor is rewritten below
     {
         float below = NEG;                                     // best key NOT collected
+        const float thr_eff = fmaxf(thr, -3.4e38f);            // thr = -inf on a tiny index: every real key (they are finite), never a missing one
         for (int64_t s = p0; s < streams; s += PF * 256) {
             uint2 two[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) { const int64_t su = s + u * 256; two[u] = su < streams ? *(const uint2*)(qkeys + su * 2) : NONE; }
+            // which of the round's 32 keys this lane collects, as a bit mask; then ONE LDS atomic per wave and round (a ballot, an
+            // atomic and a shuffle per key slot were 28k cycles of this kernel: ~50 keys pass, spread over most slots)
+            unsigned km = 0;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                const float v0 = __builtin_bit_cast(float, two[u].x), v1 = __builtin_bit_cast(float, two[u].y);
+                const bool k0 = v0 >= thr_eff, k1 = v1 >= thr_eff;
+                km |= (k0 ? 1u : 0u) << (2 * u) | (k1 ? 1u : 0u) << (2 * u + 1);
+                below = fmaxf(below, fmaxf(k0 ? NEG : v0, k1 ? NEG : v1));
+            }
+            unsigned long long holders = __ballot(km != 0);
+            if (holders) {                                      // wave-uniform
+                int total = 0, mine = 0;
+                while (holders) {                               // scalar walk over the lanes that collect something: their offsets
+                    const int l = __builtin_ctzll(holders);
+                    holders &= holders - 1;
+                    const int c = __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)km, l));
+                    if (lane == l) mine = total;
+                    total += c;
+                }
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&surv_n, total);
+                int pos = __builtin_amdgcn_readfirstlane(base) + mine;
+                if (km) {
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const float v = __builtin_bit_cast(float, w ? two[u].y : two[u].x);
-                    const bool keep = v >= thr && v > NEG;                 // (thr = -inf on a tiny index: every real key)
-                    const unsigned long long m = __ballot(keep);
-                    if (m) {                                                // one LDS atomic per wave and collected group
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&surv_n, __builtin_popcountll(m));
-                        base = __shfl(base, 0);
-                        const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                        if (keep && pos < 4 * RV_C) { sel_v[pos] = v; sel_s[pos] = (int)((s + u * 256) * 2) + w; }
+                    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            if (km >> (2 * u + w) & 1u) {
+                                if (pos < 4 * RV_C) { sel_v[pos] = __builtin_bit_cast(float, w ? two[u].y : two[u].x); sel_s[pos] = (int)((s + u * 256) * 2) + w; }
+                                ++pos;
+                            }
+                        }
                     }
-                    if (!keep) below = fmaxf(below, v);
                 }
             }
         }
