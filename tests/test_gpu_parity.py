@@ -946,6 +946,18 @@ def test_config3_full_size_properties(gpu_lib):
     assert st["verified"] + st["rescanned"] + st["exact_fallback"] == 64      # (d)
     dd = d16.cpu().numpy(); ii = ids16.cpu().numpy()
     assert np.all(np.diff(dd, axis=1) >= 0) and np.all((ii >= 0) & (ii < n))  # (b)
+    # (c) again on every scan path: one query (the reference's call pattern), 33 (two query groups per pass of the
+    # streaming scan), 300 (the 256-query MFMA tile, ragged second tile)
+    more = torch.randn((300, d), device=dev, generator=g)
+    more = more / more.norm(dim=1, keepdim=True)
+    for nq in (1, 33, 300):
+        a_i = torch.empty((nq, 10), dtype=torch.int32, device=dev); a_d = torch.empty((nq, 10), device=dev)
+        b_i = torch.empty((nq, 10), dtype=torch.int32, device=dev); b_d = torch.empty((nq, 10), device=dev)
+        idx.search_device(more.data_ptr(), nq, 10, a_i.data_ptr(), a_d.data_ptr(), mode=MODE_FP16); idx.synchronize()
+        st = idx.last_search_stats()
+        idx.search_device(more.data_ptr(), nq, 10, b_i.data_ptr(), b_d.data_ptr(), mode=MODE_EXACT); idx.synchronize()
+        assert torch.equal(a_i, b_i) and torch.equal(a_d, b_d), nq
+        assert st["verified"] + st["rescanned"] + st["exact_fallback"] == nq and st["exact_fallback"] <= 1, (nq, st)
     # (a) self-queries.  The first rows of the big index are reproduced bit for bit in a small second index
     # (same generator seed -> identical first block, same device normalisation) and exported from there.
     small = OptimizedHNSWIndex(dimension=d)
