@@ -757,7 +757,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         for (int r = 0; r < 8; ++r) {
             t8 = wave64_max(cur);
             const unsigned long long holders = __ballot(cur == t8);
-            if (lane == (int)__builtin_ctzll(holders)) cur = NEG;      // (all -inf: lane 0 "retires", nothing changes)
+            if (holders && lane == (int)__builtin_ctzll(holders)) cur = NEG;      // (all -inf: lane 0 "retires", nothing changes; none only if every key is NaN)
         }
         if (lane == 0) wave_floor[wave] = t8;
     }
