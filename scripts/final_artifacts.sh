@@ -11,9 +11,9 @@ timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench d
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver.err; echo "bench driver flags done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3 -o p -- python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-sustained > $O/bench_under_rocprof.json 2> $O/prof3.err; echo "rocprof 3-stream done"
 VQ_BENCH_CONCURRENT=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o p -- python3 bench.py --steps 30 --warmup 6 --streams 1 --no-cpu-baseline --no-sustained --no-search --no-preprocess > $O/bench_under_rocprof_1stream.json 2> $O/prof1.err; echo "rocprof 1-stream done"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err; echo "pmc fetch done"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline > /dev/null 2> $O/pmc_write.err; echo "pmc write done"
-python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json "bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline" | tail -3
+VQ_BENCH_CONCURRENT=1 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err; echo "pmc fetch done"
+VQ_BENCH_CONCURRENT=1 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline > /dev/null 2> $O/pmc_write.err; echo "pmc write done"
+python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json "VQ_BENCH_CONCURRENT=1 bench.py --steps 3 --warmup 1 --streams 1 --no-sustained --no-cpu-baseline (the kernels of the headline configuration, one batch at a time)" | tail -3
 find $O -name '*kernel_stats.csv' | while read f; do cp $f $O/$(echo $f | sed 's#.*/\(prof[13]\)/.*#\1#')_kernel_stats.csv; done
 find $O -name '*_kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -size +20M -delete
 ls -la $O
