@@ -128,10 +128,12 @@ int vq_encoder_output_dim(vq_encoder* enc, int* dim);
 /* Per-kernel-class device timing with HIP events on the encoder's stream
  * (bench.py roofline leg).  Between begin/end every launch is bracketed by
  * events; end() reports total ms and launch count per class. */
-#define VQ_ENC_NCLASS 10
+#define VQ_ENC_NCLASS 11
 int vq_encoder_profile_begin(vq_encoder* enc);
 int vq_encoder_profile_end(vq_encoder* enc, float* ms /*[VQ_ENC_NCLASS]*/, int* launches /*[VQ_ENC_NCLASS]*/);
 const char* vq_encoder_profile_class_name(int cls);
+/* Median elapsed time of an EMPTY event bracket on the encoder's stream: what a bracket adds to the kernel it holds. */
+int vq_encoder_profile_bracket_overhead(vq_encoder* enc, float* ms);
 
 /* Test hooks: run only the first `layers` transformer blocks (<0: all), and copy
  * an internal activation to the host as fp32: "x" [n*T][hidden] residual stream,

@@ -25,7 +25,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 # before the process's first HIP call; a value the caller exported wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ENC_NCLASS = 10
+ENC_NCLASS = 11
 IDX_NCLASS = 6
 
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "vq_encoder_profile_begin": (c_int, [c_void_p]),
     "vq_encoder_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
     "vq_encoder_profile_class_name": (c_char_p, [c_int]),
+    "vq_encoder_profile_bracket_overhead": (c_int, [c_void_p, POINTER(c_float)]),
     "vq_encoder_debug_set_layers": (c_int, [c_void_p, c_int]),
     "vq_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_float)]),
     "vq_text_encoder_create": (c_int, [POINTER(TextConfigC), POINTER(POINTER(c_float)), c_int, c_int, c_int, POINTER(c_void_p)]),

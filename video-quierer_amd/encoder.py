@@ -151,6 +151,13 @@ class VitEncoder:
         return {lib.vq_encoder_profile_class_name(i).decode(): {"ms": float(ms[i]), "launches": int(cnt[i])}
                 for i in range(_lib.ENC_NCLASS)}
 
+    def profile_bracket_overhead_ms(self) -> float:
+        """Median elapsed time of an empty event bracket on this handle's stream (what profile_end's figures carry per launch
+        beyond the kernel itself)."""
+        ms = c_float(0.0)
+        _lib.check(_lib.load().vq_encoder_profile_bracket_overhead(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
     def debug_set_layers(self, layers: int) -> None:
         _lib.check(_lib.load().vq_encoder_debug_set_layers(self._h, int(layers)))
 
