@@ -494,7 +494,7 @@ def test_small_batch_streaming_scan_matches_oracle_bit_exact(gpu_lib):
     rng = np.random.default_rng(41)
     vecs = rng.standard_normal((20001, 512)).astype(np.float32)       # ragged last stream (33 rows)
     qs = rng.standard_normal((96, 512)).astype(np.float32)
-    for nq, k in ((1, 10), (1, 1), (5, 20), (16, 10), (17, 10), (32, 10), (33, 5), (64, 32), (96, 10)):   # > 16: two query groups per pass
+    for nq, k in ((1, 10), (1, 1), (1, 32), (5, 20), (16, 10), (17, 10), (32, 10), (33, 5), (64, 32), (96, 10)):   # > 16: two query groups per pass
         st = _scan_vs_oracle(vecs, qs[:nq], k)
         assert k > 20 or st["exact_fallback"] <= 1, (nq, k, st)    # k = 32 = every candidate slot: the proof rarely closes, the fallback answers
     _scan_vs_oracle(vecs[:16400, :256], qs[:3, :256], 5)                # dim 256 instantiation
@@ -527,6 +527,8 @@ def test_small_batch_rescore_across_index_sizes(gpu_lib):
     tied = np.concatenate([vecs[:3000]] * 3)
     _scan_vs_oracle(tied, qs[:3], 10)
     _scan_vs_oracle(tied, vecs[:2] + 0, 6)                                # the query IS a stored row: distance ~0 three times
+    st = _scan_vs_oracle(tied, vecs[:1] + 0, 32)                          # ONE query whose proof cannot close (k = every candidate slot, ties):
+    assert st["exact_fallback"] == 1, st                                  # its own workgroup files it for the exact fallback
 
 
 def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):

@@ -710,7 +710,9 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  const float* __restrict__ rows, int64_t n_valid, int dim,
                                  const float* __restrict__ queries, int nq, int k,
                                  int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
-                                 int32_t* __restrict__ flags, float eps_rows) {
+                                 int32_t* __restrict__ flags, float eps_rows,
+                                 int32_t* __restrict__ slots1 /* with counters1: a ONE-query launch writes the flagged list and */,
+                                 int32_t* __restrict__ counters1 /* the outcome counters itself (collect_flags_kernel's job) */) {
     __shared__ float sel_v[4 * RV_C];
     __shared__ int sel_s[4 * RV_C];
     __shared__ float wave_floor[4];
@@ -988,6 +990,11 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                 rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
             if (rank < k) { out_ids[(size_t)q * k + rank] = cand_row[i]; out_dist[(size_t)q * k + rank] = cand_dist[i]; }
         }
+    }
+    if (counters1 && tid == 0) {        // nq == 1: one workgroup saw the only flag — one launch fewer on the single-query path
+        const int st = state;
+        if (st == 2) slots1[0] = 0;
+        counters1[0] = st == 2; counters1[1] = st == 0; counters1[2] = st == 1; counters1[3] = st == 2;
     }
     VQ_RS_STAMP(9);
 }

@@ -249,7 +249,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             if (ver == 3)
                 hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), (size_t)(RV_C * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
                                    x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
-                                   scan_eps_unit(x->dim) * x->row_norm_max);
+                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? x->d_counters : nullptr);
             else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
@@ -261,7 +261,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // list and the fallback kernels size themselves from its length (all of them leave at once when it is empty), so
     // nothing here waits for the stream.  Rounds beyond the first exist only when more queries could be flagged than
     // one round's scratch holds.
-    hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
+    if (!(ver == 3 && nq == 1))             // a single query's re-score workgroup has written the list and the counters itself
+        hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
     {
         Prof p(x, I_EXACT_DIST);
         hipLaunchKernelGGL(exact_fallback_kernel, dim3(fast_splits, 1), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
