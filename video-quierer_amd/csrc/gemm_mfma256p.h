@@ -310,10 +310,15 @@ template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
     // 12: 128x256 tiles, two workgroups per CU, wherever the 256x256 kernel would run (13: on every shape that tiles)
+#ifdef VQ_GEMM_EXPERIMENTS
     if ((force == 12 || force == 13) && M % G12_BM == 0 && N % G12_BN == 0 && K % (2 * G12_SUB_K) == 0 && K >= 4 * G12_SUB_K &&
         (force == 13 || (int64_t)(M / G12_BM) * (N / G12_BN) >= 256))
         return launch_gemm_tn128x256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 12 || force == 13) force = 6;
+#else       // measured and rejected mainloops are not part of the product library
+    if (force == 9 || force == 12 || force == 13)
+        return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
+#endif
     if constexpr (epi_row_in<Epi>::value) {
         // epilogues that consume per-row LayerNorm statistics need the kernels with the row-stat prologue
         const bool fits = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
@@ -327,7 +332,9 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                     return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M - m_main, N, K, epi, m_main);
                 }
             }
+#ifdef VQ_GEMM_EXPERIMENTS
             if (force == 9 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#endif
             // Three tiles of a tile row per workgroup where that still leaves >= 192 workgroups (fc1 at batch 256): the second
             // and third tile's first operands land under the previous epilogue (fc1 -3.5 % with one batch in flight, +0.5 % frames/s
             // with three; qkv would drop to 150 workgroups and lose 29 %).  Concurrent handles only: a lone batch keeps the
@@ -351,7 +358,9 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     const bool fits256 = M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0;
     if (force == 8) return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
     if (force == 11) return launch_gemm_tn256d<IS_F16, Epi, false>(st, A, lda, W, ldw, M, N, K, epi);
+#ifdef VQ_GEMM_EXPERIMENTS
     if (force == 9 && fits256 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+#endif
     if (force == 15 && fits256 && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128)
         return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
     if (force == 16 && fits256 && lda % 64 == 0 && ldw % 64 == 0)          // tests: the multi-tile kernel on any shape that tiles

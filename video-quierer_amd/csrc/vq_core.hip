@@ -88,7 +88,7 @@ int vq_init(int device_ordinal) {
 int vq_debug_gemm(const float* A, const float* W, int M, int N, int K, int flags, float* C) {
     VQ_TRY(require_init());
     VQ_CHECK(A && W && C, "vq_debug_gemm: null argument");
-    const int use_f16 = flags & 1, force = (flags >> 1) & 15;    // force: 0 auto, 1 = 128x128, 2 = four-phase, 3 = ring, 4 = persistent, 5 = 160x256 ring, 7 = four-wave 256x256
+    const int use_f16 = flags & 1, force = (flags >> 1) & 31;    // force: launch_gemm_auto's kernel ids (0 auto, 1 = 128x128, 2 = four-phase, 5 = 160x256 ring, 8 / 11 deep prefetch, 16 multi-tile, ...)
     std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
     for (size_t i = 0; i < a16.size(); ++i)
         a16[i] = use_f16 ? __builtin_bit_cast(uint16_t, (_Float16)A[i]) : f32_to_bf16_rne(A[i]);
