@@ -81,6 +81,61 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+RELAUNCH_CODE = 75          # EX_TEMPFAIL: "the native RCCL exchange could not be brought up: run me again with --exchange torch"
+
+
+def supervise(argv) -> int:
+    """N > 1 with the native exchange: every rank runs as a SUPERVISOR that never touches a GPU and a CHILD that does the
+    work.  libvq_amd opens its own RCCL communicator beside torch's; its first bring-up across processes has a deadline in
+    the child (bring_up_native).  A child that gives up exits with RELAUNCH_CODE on every rank; each supervisor then starts
+    a FRESH child with --exchange torch (new rendezvous port: the old store died with rank 0's child) and the result line
+    records which path ran.  A hung or failed bring-up therefore costs its deadline, not the run."""
+    import subprocess
+    env = dict(os.environ, VQ_BENCH_CHILD="1")
+    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + argv, env=env)
+    if rc != RELAUNCH_CODE:
+        return rc
+    sys.stderr.write(f"bench.py[rank {os.environ.get('RANK', '?')}]: native RCCL bring-up gave up; relaunching this rank with --exchange torch\n")
+    env["VQ_BENCH_EXCHANGE_NOTE"] = "relaunched after the native RCCL bring-up failed or timed out"
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "False"          # nobody serves the new port yet: rank 0's child hosts the store itself
+    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--exchange", "torch"], env=env)
+
+
+def bring_up_native(dist, torch, dev, make_comm, deadline_s):
+    """libvq_amd's RCCL communicator over the ranks of the initialised process group, or None — the SAME answer on every
+    rank.  The whole phase (id broadcast, ncclCommInitRank, the agreement all_reduce) runs against a deadline: a rank still
+    inside it when the deadline passes leaves the process with RELAUNCH_CODE, and so does every rank when any rank failed."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(deadline_s):
+            sys.stderr.write(f"bench.py[rank {dist.get_rank()}]: native RCCL bring-up still not done after {deadline_s:.0f} s\n")
+            sys.stderr.flush()
+            os._exit(RELAUNCH_CODE)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    comm, err = None, None
+    try:
+        if os.environ.get("VQ_BENCH_FAKE_NATIVE_HANG") == str(dist.get_rank()):       # tests: a bring-up that never returns
+            time.sleep(3600)
+        comm = make_comm()
+    except Exception as e:                                 # noqa: BLE001 - reported, then every rank leaves together
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if comm is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    done.set()
+    if int(ok.item()) == 0:
+        if err:
+            sys.stderr.write(f"bench.py[rank {dist.get_rank()}]: native RCCL bring-up failed: {err}\n")
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+        sys.exit(RELAUNCH_CODE)
+    return comm
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,8 +154,8 @@ def parse():
     ap.add_argument("--no-sustained", action="store_true", help="skip the 50,000-frame configs[1] job after the timed steps")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (~15 s of host work)")
     ap.add_argument("--dtype", default=None,
-                    help="GEMM operand types: bf16 | fp16 | mixed | fp16:<group>+... (default: mixed for ViT-B/32 - fp16 with the "
-                         "patch-embed GEMM in bf16, DESIGN.md §2 - and fp16 for ViT-L/14@336 as configs[4] names)")
+                    help="GEMM operand types: bf16 | fp16 | mixed | fp16:<group>+... (default: fp16 = every GEMM group on fp16 MFMA "
+                         "operands, the type that reproduces the reference's id lists on config 1, DESIGN.md §2)")
     ap.add_argument("--model", choices=["b32", "l14"], default="b32",
                     help="b32 = CLIP ViT-B/32 @224 (the headline config); l14 = ViT-L/14 @336 (configs[4] model; use --batch 32)")
     ap.add_argument("--search-dim", type=int, default=512)
@@ -135,6 +190,21 @@ def rehearse_cpu(args):
         dist.init_process_group("gloo")
     if os.environ.get("VQ_BENCH_REHEARSE_FAIL_RANK") == str(rank):
         raise RuntimeError("rehearsal: this rank was told to fail")
+    exchange = "torch.distributed (gloo)"
+    if os.environ.get("VQ_BENCH_EXCHANGE_NOTE"):
+        exchange += " [%s]" % os.environ["VQ_BENCH_EXCHANGE_NOTE"]
+    if world > 1 and args.exchange == "native":
+        # the bring-up protocol of the GPU path (deadline, agreement, RELAUNCH_CODE) around a stand-in communicator
+        class _StandIn:
+            def close(self):
+                pass
+
+        def make():
+            if os.environ.get("VQ_BENCH_FAKE_NATIVE_FAIL") == str(rank):
+                raise RuntimeError("rehearsal: this rank cannot bring the native exchange up")
+            return _StandIn()
+        bring_up_native(dist, torch, torch.device("cpu"), make, float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120")))
+        exchange = "stand-in for libvq_amd vq_comm_* (rehearsal)"
     g = torch.Generator().manual_seed(rank)
 
     def step():
@@ -160,6 +230,7 @@ def rehearse_cpu(args):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * float(t.item()) / args.steps, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic", "rehearsal": True,
+                          "world": {"size": world, "backend": "gloo", "exchange": exchange},
                           "config": {"workload": "CPU rehearsal of the multi-rank control flow (no GPU work)",
                                      "gathered_rows": int(rows.shape[0]), "merged_ids": int(gid.numel())}}), flush=True)
     if world > 1:
@@ -172,10 +243,13 @@ def main():
     BATCH = args.batch
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))          # before anything touches a GPU
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.exchange == "native" and os.environ.get("VQ_BENCH_CHILD") != "1"
+            and (os.environ.get("VQ_BENCH_BACKEND", "nccl") == "nccl" or args.rehearse_cpu)):
+        sys.exit(supervise(sys.argv[1:]))          # this process stays off the GPU; the child it starts does the work
     if args.rehearse_cpu:
         return rehearse_cpu(args)
     if args.dtype is None:
-        args.dtype = "fp16" if args.model == "l14" else "mixed"
+        args.dtype = "fp16"          # the library default (encoder.DEFAULT_COMPUTE_DTYPE): every GEMM group on fp16 MFMA operands
     import torch
     import torch.distributed as dist
 
@@ -207,18 +281,13 @@ def main():
     comm, exchange = None, "none (single GPU)"
     if world > 1:
         exchange = "torch.distributed (%s)" % backend
+        if os.environ.get("VQ_BENCH_EXCHANGE_NOTE"):
+            exchange += " [%s]" % os.environ["VQ_BENCH_EXCHANGE_NOTE"]
         if args.exchange == "native" and backend == "nccl":
-            try:
-                from video_quierer_amd.comm import Comm
-                comm = Comm.from_torch_distributed(local)
-                exchange = "libvq_amd vq_comm_* over RCCL %d" % comm.rccl_version()
-            except Exception as e:                     # noqa: BLE001 - recorded in the result line
-                exchange += f" [native RCCL init failed: {e}]"
-        ok = torch.tensor([1 if comm is not None else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # all ranks take the same path
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+            from video_quierer_amd.comm import Comm
+            comm = bring_up_native(dist, torch, dev, lambda: Comm.from_torch_distributed(local),
+                                   float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120")))
+            exchange = "libvq_amd vq_comm_* over RCCL %d" % comm.rccl_version()
     cfg = VIT_L_14_336 if args.model == "l14" else VIT_B_32
     flop_per_frame = 2 * cfg.macs_per_frame()
     weights = seeded_weights(cfg, 1234)
@@ -305,7 +374,7 @@ def main():
         "metric": METRIC, "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "fp16": "fp16", "mixed": "fp16 MFMA operands (bf16 for the patch-embed GEMM), fp32 accumulate"}.get(args.dtype, args.dtype),
+        "dtype": {"bf16": "bf16", "fp16": "fp16 MFMA operands (every GEMM group), fp32 accumulate", "mixed": "fp16 MFMA operands (bf16 for the patch-embed GEMM), fp32 accumulate"}.get(args.dtype, args.dtype),
         "data": "synthetic",
         "config": {"workload": (f"configs[1]: batch-{BATCH} ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
                                 if args.model == "b32" else

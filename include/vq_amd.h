@@ -67,13 +67,15 @@ typedef struct vq_vit_config {
  * max_batch: frames per device pass (workspace is sized for it). */
 int vq_encoder_create(const vq_vit_config* cfg, const float* const* weights, int n_weights,
                       int max_batch, vq_encoder** out);
-/* Same with flags: VQ_ENC_FP16 = fp16 instead of bf16 GEMM operands (same MFMA rate, ~8x smaller
- * rounding error; the type ViT-L/14@336 is specified with).  $VQ_AMD_DTYPE=fp16|bf16 overrides. */
+/* Same with flags: VQ_ENC_FP16 = fp16 instead of bf16 GEMM operands in every group (same MFMA rate, ~8x smaller
+ * rounding error; what the Python host passes by default and the type ViT-L/14@336 is specified with; the patch
+ * weights W/(255 std) are scaled by a power of two out of fp16's subnormal range and the scale is undone, exactly,
+ * in the GEMM epilogue).  $VQ_AMD_DTYPE=fp16|bf16 overrides. */
 #define VQ_ENC_FP16 1
 /* Operand type per GEMM group (set = fp16, clear = bf16; fp32 accumulation and the same MFMA rate either way):
  * PATCH = pixels x W_patch, QKV = LN1 output x W_qkv, ATTN = q|k|v, softmax P, attention output x W_out,
- * FC1 = LN2 output x W_fc1, FC2 = quick-GELU output x W_fc2.  VQ_ENC_MIXED is the build's default for
- * ViT-B/32 (which roundings the 1e-3 score tolerance can afford).  $VQ_AMD_DTYPE =
+ * FC1 = LN2 output x W_fc1, FC2 = quick-GELU output x W_fc2.  VQ_ENC_MIXED (all but the patch GEMM) was round 2's
+ * default (which roundings the 1e-3 score tolerance can afford).  $VQ_AMD_DTYPE =
  * bf16 | fp16 | mixed | mask:<bits 0-4> overrides the flags. */
 #define VQ_ENC_F16_PATCH 0x100
 #define VQ_ENC_F16_QKV 0x200
@@ -171,21 +173,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
 int vq_text_encoder_encode_ids(vq_text_encoder* enc, const int32_t* ids, int n, int seq_len, float* out);
 int vq_text_encoder_destroy(vq_text_encoder* enc);
 
-/* Diagnostic build of the 256x256 mainloop with in-kernel s_memtime stamps: workgroup 0, 8 waves x
- * 768 stamps (3 per phase: start of read half, after the first barrier, after the MFMAs).
- * diag: bit0 skip the in-loop DMA, bit1 skip the ds_reads, bit2 skip the MFMAs (timing ablations; results invalid). */
-int vq_debug_gemm_stamps(int M, int N, int K, int diag, unsigned long long* stamps);
-
-/* Diagnostic: average time of one GEMM mainloop with parts removed (results invalid).  kernel: 1 =
- * 128x128, 2 = 256x256 four-phase, 3 = 256x256 ring; diag: bit0 no in-loop DMA, bit1 no ds_reads,
- * bit2 no MFMAs, bit3 no barriers (ring only). */
-int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, float* ms_avg);
-/* Diagnostic: average launch time of the deep-prefetch 256x256 mainloop on random data and the clock (GHz) the chip
- * holds inside its K loop (d s_memtime / d s_memrealtime, median over workgroups). */
-int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz_median);
-/* Diagnostic: s_memtime stamps of workgroup 0 of that mainloop, four per phase (phase start, before the mid barrier,
- * before the MFMAs, after them): stamps[8 waves][512]. */
-int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long* stamps);
+/* Mainloop stamps / ablations / clock probes are not product entry points: include/vq_amd_diag.h (`make DIAG=1`). */
 
 /* ---- index: HNSWIndex.add / search / size / save / load --------------------- */
 typedef struct vq_index vq_index;
@@ -204,17 +192,27 @@ int vq_index_destroy(vq_index* idx);
  * mode 2 is refused. */
 int vq_index_add(vq_index* idx, const float* rows, int64_t n, int normalize);
 int vq_index_add_device(vq_index* idx, const void* d_rows_f32, int64_t n, int normalize);
+/* Re-add of an id the index already holds (hnsw.py:160 `self.data[node_id] = vector`: a dict assignment): replaces
+ * stored rows IN PLACE — fp32 master, fp16 scan copy and the |row|^2 range — without touching the other rows.
+ * rows [n][dim] (host), row_numbers [n] in [0, size).  A row named more than once keeps its LAST update, as the
+ * reference's sequential assignments do.  normalize as vq_index_add.  The result is bit-identical to an index built
+ * from scratch with the updated rows.  Synchronous. */
+int vq_index_update_rows(vq_index* idx, const float* rows, const int64_t* row_numbers, int64_t n, int normalize);
 int vq_index_size(vq_index* idx, int64_t* n);
 int vq_index_clear(vq_index* idx);
 
 /* search / search_batch (hnsw.py:238-300, 488-528) as an exact scan:
  *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row).
- * queries [nq][dim] are used as given (the wrapper does query / ||query|| with numpy, hnsw.py:250); the
- * fp16 path's exactness bound scales with each query's own norm, so un-normalised queries stay exact.  ids/dist are [nq][k]; unused slots
+ * queries [nq][dim] are used as given (the wrapper does query / ||query|| with numpy, hnsw.py:250).  The
+ * fp16 path's exactness bound scales with each query's own norm while 0.25 <= |q|^2 <= 4; a query outside that
+ * range (or not finite) is outside what fp16 operands can bound and is answered by the exact scan instead
+ * (device-side fallback), so un-normalised queries stay exact at any scale.  ids/dist are [nq][k]; unused slots
  * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 32), 1 exact
  * fp32-master scan, 2 fp16 MFMA scan + exact re-score with proof (unproven queries are redone by the
  * exact scan, on the device: nothing is read back).  vq_index_search_device is asynchronous on the index's
- * stream in every mode; vq_index_last_search_stats waits for that stream. */
+ * stream in every mode, with one exception: the first search after a vq_index_add_device(normalize=0) waits
+ * for the stream once to read the |row|^2 range those rows were measured at (the host-side adds read it
+ * before they return).  vq_index_last_search_stats waits for that stream. */
 int vq_index_search(vq_index* idx, const float* queries, int nq, int k, int mode,
                     int32_t* ids, float* dist);
 int vq_index_search_device(vq_index* idx, const void* d_queries_f32, int nq, int k, int mode,

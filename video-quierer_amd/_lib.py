@@ -71,12 +71,11 @@ SIGNATURES = {
     "vq_text_encoder_encode_ids": (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, POINTER(c_float)]),
     "vq_text_encoder_destroy": (c_int, [c_void_p]),
     "vq_debug_gemm": (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, POINTER(c_float)]),
-    "vq_debug_gemm_stamps": (c_int, [c_int, c_int, c_int, c_int, POINTER(ctypes.c_uint64)]),
-    "vq_debug_gemm_ablate": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_index_create": (c_int, [c_int, POINTER(c_void_p)]),
     "vq_index_destroy": (c_int, [c_void_p]),
     "vq_index_add": (c_int, [c_void_p, POINTER(c_float), c_int64, c_int]),
     "vq_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "vq_index_update_rows": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int64), c_int64, c_int]),
     "vq_index_size": (c_int, [c_void_p, POINTER(c_int64)]),
     "vq_index_clear": (c_int, [c_void_p]),
     "vq_index_search": (c_int, [c_void_p, POINTER(c_float), c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
@@ -100,8 +99,6 @@ SIGNATURES = {
     "vq_resampler_run_u8_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vq_resampler_device_output": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "vq_clip_processor_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
-    "vq_debug_gemm_clock": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
-    "vq_debug_gemm_stamps_deep": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "vq_comm_unique_id": (c_int, [c_void_p, c_int]),
     "vq_comm_init": (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "vq_comm_destroy": (c_int, [c_void_p]),
@@ -112,24 +109,34 @@ SIGNATURES = {
     "vq_frame_quality_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
 }
 
+# include/vq_amd_diag.h: present only in a `make DIAG=1` build (scripts/ point $VQ_AMD_LIB at one); bound when found
+DIAG_SIGNATURES = {
+    "vq_debug_gemm_stamps": (c_int, [c_int, c_int, c_int, c_int, POINTER(ctypes.c_uint64)]),
+    "vq_debug_gemm_ablate": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]),
+    "vq_debug_gemm_clock": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "vq_debug_gemm_stamps_deep": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
+    "vq_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
+}
+
 _lock = threading.Lock()
 _lib = None
 _device = None
 
 
 def build(force: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into lib/libvq_amd.so (hipcc cross-compiles without a GPU).  Serialised by
-    a file lock: under torch.distributed.run every rank may find the library missing at the same moment; the
-    Makefile links to a temporary name and renames, so a concurrent dlopen never sees a half-written file."""
+    """Compile csrc/*.hip for gfx950 into lib/libvq_amd.so (hipcc cross-compiles without a GPU).  Always runs make — it is
+    incremental, so an edited kernel never leaves a stale library behind.  Serialised by a file lock: under
+    torch.distributed.run every rank may find the library missing at the same moment; the Makefile links to a temporary
+    name and renames, so a concurrent dlopen never sees a half-written file.  Builds the DEFAULT library only: a path given
+    in $VQ_AMD_LIB is somebody else's build and is never (re)made here."""
     import fcntl
     with open(os.path.join(CSRC_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or not os.path.exists(LIB_PATH):
-                subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else []))
+            subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else []))
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB_PATH
+    return os.path.join(_HERE, "lib", "libvq_amd.so")
 
 
 def load() -> ctypes.CDLL:
@@ -137,6 +144,8 @@ def load() -> ctypes.CDLL:
     global _lib
     with _lock:
         if _lib is None:
+            if not os.path.exists(LIB_PATH) and os.environ.get("VQ_AMD_LIB"):
+                raise VqError(f"$VQ_AMD_LIB points at {LIB_PATH}, which does not exist (it is never built automatically)")
             if not os.path.exists(LIB_PATH):
                 # a fresh checkout has sources only: build in place if the toolchain is here (hipcc
                 # cross-compiles gfx950 without a GPU); never substitute anything else for the library
@@ -149,6 +158,10 @@ def load() -> ctypes.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)      # AttributeError here = header/library mismatch
                 fn.restype, fn.argtypes = res, args
+            for name, (res, args) in DIAG_SIGNATURES.items():
+                fn = getattr(lib, name, None)
+                if fn is not None:
+                    fn.restype, fn.argtypes = res, args
             _lib = lib
     return _lib
 

@@ -39,9 +39,20 @@ class Comm:
         """Bootstrap over an initialised torch.distributed group (its store carries the id; no tensor traffic)."""
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.make_unique_id() if rank == 0 else None]
+        # Rank 0 ALWAYS takes part in the broadcast: if it cannot make the id (librccl not loadable, ncclGetUniqueId
+        # failing) it ships the error instead, and every rank raises — nobody is left waiting in a collective its peers
+        # never enter (bench.py then agrees on the torch.distributed exchange with one all_reduce).
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("ok", cls.make_unique_id())]
+            except Exception as e:                    # noqa: BLE001 - forwarded to every rank
+                box = [("err", f"{type(e).__name__}: {e}")]
         dist.broadcast_object_list(box, src=0)
-        return cls(rank, world, box[0], device)
+        tag, payload = box[0]
+        if tag != "ok":
+            raise _lib.VqError(f"rank 0 could not create the RCCL bootstrap id: {payload}")
+        return cls(rank, world, payload, device)
 
     @classmethod
     def single(cls, device: Optional[int] = None) -> "Comm":

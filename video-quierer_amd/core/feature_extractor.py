@@ -14,9 +14,10 @@ What differs from the reference, deliberately:
 * Frames that are not 224x224 are resized on the GPU, bit-identically to Pillow (preprocess.py);
   ``resize_mode="clip_processor"`` selects the live path's short-edge-bicubic + centre-crop instead of the
   reference class's stretch.
-* GEMMs take 16-bit operands with fp32 accumulation: ``compute_dtype="mixed"`` (default: fp16, the
-  patch-embed GEMM in bf16), ``"bf16"``, ``"fp16"`` or ``"fp16:<group>+…"`` (encoder.py); every cosine score
-  agrees with the fp32 reference within 1e-3 at the default (tests/test_gpu_parity.py).
+* GEMMs take 16-bit operands with fp32 accumulation: ``compute_dtype="fp16"`` (default: every GEMM group),
+  ``"mixed"`` (the patch-embed GEMM in bf16), ``"bf16"`` or ``"fp16:<group>+…"`` (encoder.py); at the default every
+  cosine score agrees with the fp32 reference within 1e-3 and config 1's id lists equal the reference's
+  (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 

@@ -205,7 +205,7 @@ struct EpiSplitKPartialF32 {
 };
 
 // x[m*tokens][n] += bias[n] + sum over slices (in slice order) of part[s][m][n], m < m_valid     (last block's fc2, CLS rows)
-__global__ __launch_bounds__(256)
+inline __global__ __launch_bounds__(256)
 void splitk_reduce_residual_cls_kernel(const float* __restrict__ part, int64_t plane, int splits, float* __restrict__ x,
                                        const float* __restrict__ bias, int hidden, int tokens, int m_valid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one float4 of one CLS row
@@ -220,8 +220,10 @@ void splitk_reduce_residual_cls_kernel(const float* __restrict__ part, int64_t p
 
 // Patch-embedding GEMM: GEMM row m = (image b, patch p) -> token row b*T + 1 + p;
 // x = acc + folded_bias + position_embedding[1+p]          (E3)
+// `unscale` = 2^-s undoes the power-of-two scale the host put on fp16 patch weights (vq_encoder.hip: W/(255 std) sits in
+// fp16's subnormal range unscaled); a power of two, so acc * unscale is exact.  1 for bf16 weights.
 struct EpiPatchEmbedF32 {
-    float* x; int hidden; const float* bias; const float* pos; int patches; int tokens; int m_valid;
+    float* x; int hidden; const float* bias; const float* pos; int patches; int tokens; int m_valid; float unscale = 1.0f;
     static constexpr bool kLoads = true;
     __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
     __device__ __forceinline__ f32x4 load(int m, int n) const {
@@ -232,7 +234,7 @@ struct EpiPatchEmbedF32 {
     __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4 b, f32x4 pp) const {
         if (m >= m_valid) return;
         const int bimg = m / patches, p = m - bimg * patches;
-        *(f32x4*)(x + ((size_t)bimg * tokens + 1 + p) * hidden + n) = v + b + pp;
+        *(f32x4*)(x + ((size_t)bimg * tokens + 1 + p) * hidden + n) = v * unscale + b + pp;
     }
 };
 
@@ -382,7 +384,7 @@ void embed_finish_kernel(float* __restrict__ x, uint16_t* __restrict__ xh,
 }
 
 // rows r*stride of a 16-bit [.][cols] matrix -> compact rows r (CLS gather for the last block)
-__global__ __launch_bounds__(256)
+inline __global__ __launch_bounds__(256)
 void gather_rows_h16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int rows, int cols, int stride) {
     const int per_row = cols / 8;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * per_row; i += gridDim.x * blockDim.x) {
@@ -417,7 +419,7 @@ void embed_tokens_kernel(const int* __restrict__ ids, const float* __restrict__ 
 
 // pooling row of every sequence (tf:568-586): first position holding eos_token_id (position 0 if none);
 // for the legacy eos_token_id == 2 checkpoints, the position of the largest id.
-__global__ void eos_rows_kernel(const int* __restrict__ ids, int* __restrict__ row_index, int n, int seq, int eos_id) {
+inline __global__ void eos_rows_kernel(const int* __restrict__ ids, int* __restrict__ row_index, int n, int seq, int eos_id) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int* p = ids + (size_t)s * seq;
@@ -1015,7 +1017,7 @@ void pool_project_kernel(const float* __restrict__ x, const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256)
+inline __global__ __launch_bounds__(256)
 void l2_normalize_rows_kernel(float* __restrict__ feat, uint16_t* __restrict__ out_f16, int n_images, int proj_dim) {
     const int lane = threadIdx.x & 63;
     const int img = blockIdx.x * 4 + (threadIdx.x >> 6);

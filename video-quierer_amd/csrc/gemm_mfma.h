@@ -133,6 +133,17 @@ __device__ __forceinline__ Epi epi_bind_rowstats(const Epi& epi, float2* lds_sta
     return e;
 }
 
+// C = acc, fp32 (unit-test hook vq_debug_gemm and the diagnostic timers)
+struct EpiStoreF32 {
+    float* out; int ldo;
+    static constexpr bool kLoads = false;
+    __device__ __forceinline__ f32x4 bias_at(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, f32x4, f32x4) const {
+        *(f32x4*)(out + (size_t)m * ldo + n) = v;
+    }
+};
+
 struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `after_loads()` runs once, right behind the epilogue's first global loads (per-column constants, first residual rows):

@@ -26,6 +26,7 @@
 #include "gemm_mfma256w4.h"
 #include "gemm_mfma256d.h"
 #include "gemm_mfma128x256.h"
+#include "gemm_mfma128x256p.h"
 #include "gemm_mfma256f.h"
 
 namespace vq {
@@ -309,6 +310,11 @@ static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one 
 template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
+    // 20 / 21: persistent out-of-phase 128x256 tiles, two workgroups per CU (gemm_mfma128x256p.h), on every shape that tiles
+    // (20: the second workgroup of a CU starts half a tile late; 21: no lag — the in-step control of the A/B)
+    if ((force == 20 || force == 21) && M % GP_BM == 0 && N % GP_BN == 0 && K % (2 * GP_SUB_K) == 0 && K >= 4 * GP_SUB_K)
+        return launch_gemm_tn128x256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, force == 20 ? 1 : 0, gp_dephase_cycles(K));
+    if (force == 20 || force == 21) force = 6;
     // 12: 128x256 tiles, two workgroups per CU, wherever the 256x256 kernel would run (13: on every shape that tiles)
 #ifdef VQ_GEMM_EXPERIMENTS
     if ((force == 12 || force == 13) && M % G12_BM == 0 && N % G12_BN == 0 && K % (2 * G12_SUB_K) == 0 && K >= 4 * G12_SUB_K &&

@@ -80,6 +80,26 @@ void rows_to_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ ds
     }
 }
 
+// In-place replacement of stored rows (HNSWIndex.add of an id that is already there, hnsw.py:160 `self.data[node_id] =
+// vector`): src[i] -> rows[row_no[i]] (fp32 master) and its fp16 scan copy, the same conversion as rows_to_f16_kernel, so an
+// updated matrix is bit-identical to one built from scratch.  row_no holds distinct row numbers (the host drops all but the
+// last update of a row).  One thread per float4.
+__global__ __launch_bounds__(256)
+void scatter_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ row_no, int64_t n, int dim,
+                         float* __restrict__ rows, uint16_t* __restrict__ rows16) {
+    const int per_row = dim >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * per_row; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row) * 4;
+        const float4 v = *(const float4*)(src + r * dim + c);
+        const int64_t dst = row_no[r] * dim + c;
+        *(float4*)(rows + dst) = v;
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *(uint2*)(rows16 + dst) = __builtin_bit_cast(uint2, h);
+    }
+}
+
 // ---- exact distances ----
 // Workgroup tile: 64 rows x 32 queries, 256 threads; thread (r = tid&63, g = tid>>6)
 // owns row r and queries 8g..8g+7 (a wave shares g, so query reads are LDS broadcasts).

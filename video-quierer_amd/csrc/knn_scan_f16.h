@@ -44,6 +44,14 @@ constexpr int SCAN_STREAM_ROWS = 128; // rows seen by one lane stream
 //   2^-16             index bits packed into the low mantissa bits of the key
 //   2 * sqrt(dim) * 2^-25   elements below the fp16 normal range (absolute, not relative, rounding)
 // plus 2 % for the fp32 arithmetic that evaluates the bound itself.  1.07e-3 at dim 512, 1.5e-3 at dim 4096.
+// The bound above is RELATIVE to |row| |q| except for its last term, and the query is converted to fp16 as given: far below
+// unit norm its elements land in fp16's subnormal / flush range, where the rounding error is absolute and does not shrink
+// with |q| (at |q| ~ 1e-5 it already exceeds the scaled bound); far above, elements overflow to inf and the packed keys
+// become NaN, which v_max drops.  Queries with |q|^2 outside [0.25, 4] (or not finite) are therefore never "proven": the
+// re-score kernels file them as state 2 and the exact scan answers them.  The Python hosts normalise their queries
+// (hnsw.py:250), so only raw C-ABI callers meet this.
+constexpr float SCAN_Q2_MIN = 0.25f, SCAN_Q2_MAX = 4.0f;
+
 static inline float scan_eps_unit(int dim) {
     const double e = 2.0 / 2048 + 1.0 / 4194304 + dim / 8388608.0 + 1.0 / 65536 + 2.0 * __builtin_sqrt((double)dim) / 33554432.0;
     return (float)(e * 1.02);
@@ -608,8 +616,8 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         int st = 0;
         const bool all_rows_scored = n_valid <= 0;
         (void)all_rows_scored;
-        if (have < kk) {
-            st = 2;                                            // fewer than k distinct rows among the candidates
+        if (have < kk || !(q2 >= SCAN_Q2_MIN && q2 <= SCAN_Q2_MAX)) {
+            st = 2;                                            // fewer than k distinct rows among the candidates, or a query the fp16 bound does not cover
         } else {
             if (!(bound_rest[qq] + SCAN_EPS < sk)) st = 2;     // kept keys outside the best C could still matter
             for (int sh = 0; sh < RV_SHARES; ++sh)
@@ -934,7 +942,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         if (tid >= limit && tid < RV_C) cand_row[tid] = -1;    // not re-scored: not part of the pool
         if (lane == 0) {
             int st = 0, nres = 0;
-            if (have < kk || surv_n > 4 * RV_C) st = 2;      // (more keys tied at the selection threshold than the list holds)
+            if (have < kk || surv_n > 4 * RV_C || !(qnorm2_s >= SCAN_Q2_MIN && qnorm2_s <= SCAN_Q2_MAX)) st = 2;      // (more keys tied at the selection threshold than the list holds; a query the fp16 bound does not cover)
             else {
                 if (!(bound_rest_s + eps < sk)) st = 2;            // a key outside the best C could still matter
                 if (st == 0) {

@@ -85,6 +85,7 @@ struct vq_encoder {
     float* tok_emb = nullptr; int* d_ids = nullptr; int* d_rowidx = nullptr; int vocab = 0, eos_id = 0;
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
+    float patch_unscale = 1.0f;   // 2^-s: undoes the power-of-two scale on fp16 patch weights (EpiPatchEmbedF32)
     int f16_mask = 0;        // per-GEMM-group operand type, DT_* bits (set = fp16, clear = bf16): create flags / $VQ_AMD_DTYPE
     bool h_is_f16 = false;   // type of what `h` holds right now (debug_read)
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles, 6 = auto without 160-row tiles
@@ -267,7 +268,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         Prof p(e, C_GEMM_PATCH);
         VQ_TRY(by_f16(fP, [&](auto F) {
             return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
-                                               EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows}, e->gemm_force);
+                                               EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows, e->patch_unscale}, e->gemm_force);
         }));
     }
     {   // CLS row, pre_layrnorm (in place); xh + row partials for the LN1 folded into layer 0's qkv GEMM
@@ -497,12 +498,25 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
         const int pp = c.patch_size * c.patch_size;
         std::vector<uint16_t> w16(H * patch_k);
         std::vector<float> bias(H);
+        // fp16 patch weights: W/(255 std) ~ 1e-4 for trained and seeded weights alike, i.e. inside fp16's subnormal range
+        // (< 6.1e-5 loses mantissa bits).  Scale by the power of two that puts the largest |W'| just under 2^14; the GEMM
+        // epilogue multiplies the fp32 accumulator by 2^-s (exact).  bf16 has fp32's exponent range: no scale.
+        int pshift = 0;
+        if (e->f16_mask & DT_PATCH) {
+            double amax = 0.0;
+            for (size_t n = 0; n < H; ++n)
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int i = 0; i < pp; ++i) amax = std::max(amax, std::fabs((double)wp[(n * 3 + ch) * pp + i]) / (255.0 * stdv[ch]));
+            if (amax > 0.0 && std::isfinite(amax)) pshift = std::min(24, std::max(0, (int)std::floor(std::log2(16000.0 / amax))));
+        }
+        e->patch_unscale = (float)std::ldexp(1.0, -pshift);
+        const double pscale = std::ldexp(1.0, pshift);
         for (size_t n = 0; n < H; ++n) {
             double b = 0.0;
             for (int ch = 0; ch < 3; ++ch)
                 for (int i = 0; i < pp; ++i) {
                     const double w = wp[(n * 3 + ch) * pp + i];
-                    w16[n * patch_k + ch * pp + i] = (e->f16_mask & DT_PATCH) ? __builtin_bit_cast(uint16_t, (_Float16)(float)(w / (255.0 * stdv[ch])))
+                    w16[n * patch_k + ch * pp + i] = (e->f16_mask & DT_PATCH) ? __builtin_bit_cast(uint16_t, (_Float16)(float)(w * pscale / (255.0 * stdv[ch])))
                                                              : f32_to_bf16_rne((float)(w / (255.0 * stdv[ch])));
                     b += w * (128.0 / 255.0 - mean[ch]) / stdv[ch];
                 }
@@ -556,6 +570,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->cfg = c; e->tokens = parent->tokens; e->patches = parent->patches; e->grid = parent->grid; e->patch_k = parent->patch_k;
     e->max_batch = max_batch;
     e->f16_mask = parent->f16_mask;                          // the weights are already stored in these types
+    e->patch_unscale = parent->patch_unscale;
     e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     e->attn_simple = parent->attn_simple; e->prune_last = parent->prune_last;

@@ -9,6 +9,7 @@
 #include "knn_scan_deep.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -34,6 +35,7 @@ struct vq_index {
     float* d_dist = nullptr; int64_t dist_cap = 0;    // exact distances (elements)
     uint64_t* d_partial = nullptr; int64_t partial_cap = 0;   // per-chunk top-k keys
     int32_t* d_ids = nullptr; float* d_out = nullptr; int64_t out_cap = 0;
+    float* d_upd = nullptr; int64_t upd_cap = 0;      // vq_index_update_rows: staged rows [n][dim] + their row numbers behind them
     // fp16 scan scratch
     uint16_t* d_q16 = nullptr; int64_t q16_cap = 0;
     uint32_t* d_keys = nullptr; int64_t keys_cap = 0;
@@ -132,6 +134,20 @@ int finish_add(vq_index* x, int64_t n, int normalize) {
     return 0;
 }
 
+// |row|^2 range -> near_unit / row_norm_max.  Blocks on the stream: called where the entry point blocks anyway (vq_index_add,
+// vq_index_update_rows) so that searches after a host add stay asynchronous; the device-side add leaves it to the first search.
+int refresh_norm_range(vq_index* x) {
+    if (!x->norm_dirty) return 0;
+    uint32_t range[2];
+    VQ_HIP(hipMemcpyAsync(range, x->d_norm_range, 8, hipMemcpyDeviceToHost, x->stream));
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    const float lo = __builtin_bit_cast(float, range[0]), hi = __builtin_bit_cast(float, range[1]);
+    x->near_unit = lo >= 0.5f && hi <= 2.0f;
+    x->row_norm_max = hi > 1.0f ? sqrtf(hi) * 1.0001f : 1.0001f;
+    x->norm_dirty = false;
+    return 0;
+}
+
 // Exact scan: fp64-chain distances for a slice of queries into d_dist, then selection.
 int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
     const int64_t n = x->size;
@@ -196,7 +212,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, std::max<int64_t>(fb_cap * fb_splits, (int64_t)FB_FAST_SLOTS * fast_splits) * k));
     const int ranges = (int)(n_pad / RANGE);
     if (ver == 3) {
-        static bool attr3_set = false;
+        static std::atomic<bool> attr3_set{false};
         if (!attr3_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)rescore_verify_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (RV_C * (768 + 4) + 768) * 4));
@@ -204,7 +220,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
     }
     if (ver == 2 || ver == 4) {
-        static bool attr_set = false;
+        static std::atomic<bool> attr_set{false};
         if (!attr_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)scan2_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G2_LDS_BYTES));
@@ -284,15 +300,9 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 
 int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
     VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
-    if (x->norm_dirty && mode != 1) {          // rows were added un-normalised since the last look: is the matrix still near-unit?
-        uint32_t range[2];
-        VQ_HIP(hipMemcpyAsync(range, x->d_norm_range, 8, hipMemcpyDeviceToHost, x->stream));
-        VQ_HIP(hipStreamSynchronize(x->stream));
-        const float lo = __builtin_bit_cast(float, range[0]), hi = __builtin_bit_cast(float, range[1]);
-        x->near_unit = lo >= 0.5f && hi <= 2.0f;
-        x->row_norm_max = hi > 1.0f ? sqrtf(hi) * 1.0001f : 1.0001f;
-        x->norm_dirty = false;
-    }
+    // rows were added un-normalised ON THE DEVICE since the last look (vq_index_add_device: the one add that does not block):
+    // is the matrix still near-unit?  This is the only place a search waits for its stream.
+    if (mode != 1) VQ_TRY(refresh_norm_range(x));
     const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_C && x->size >= 1 && x->near_unit;
     if (mode == 2) VQ_CHECK(fp16_ok, "vq_index_search: fp16 scan needs dim %% 64 == 0, k <= %d and near-unit rows "
                                      "(0.5 <= |row|^2 <= 2; rows added with normalize=0 are measured)", RV_C);
@@ -347,7 +357,7 @@ int vq_index_destroy(vq_index* x) {
     (void)hipFree(x->rows); (void)hipFree(x->rows16); (void)hipFree(x->d_q); (void)hipFree(x->d_dist);
     (void)hipFree(x->d_ids); (void)hipFree(x->d_out); (void)hipFree(x->d_partial);
     (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
-    (void)hipFree(x->d_counters); (void)hipFree(x->d_fb_partial);
+    (void)hipFree(x->d_counters); (void)hipFree(x->d_fb_partial); (void)hipFree(x->d_upd);
     if (x->h_counters) (void)hipHostFree(x->h_counters);
     (void)hipFree(x->d_norm_range);
     delete x;
@@ -382,6 +392,7 @@ int vq_index_add(vq_index* x, const float* rows, int64_t n, int normalize) {
     VQ_TRY(reserve_rows(x, x->size + n));
     VQ_HIP(hipMemcpyAsync(x->rows + x->size * x->dim, rows, (size_t)n * x->dim * 4, hipMemcpyHostToDevice, x->stream));
     VQ_TRY(finish_add(x, n, normalize));
+    VQ_TRY(refresh_norm_range(x));                // this call blocks anyway: searches that follow need not
     VQ_HIP(hipStreamSynchronize(x->stream));
     return 0;
 }
@@ -395,6 +406,68 @@ int vq_index_add_device(vq_index* x, const void* d_rows, int64_t n, int normaliz
     VQ_TRY(reserve_rows(x, x->size + n));
     VQ_HIP(hipMemcpyAsync(x->rows + x->size * x->dim, d_rows, (size_t)n * x->dim * 4, hipMemcpyDeviceToDevice, x->stream));
     return finish_add(x, n, normalize);
+}
+
+int vq_index_update_rows(vq_index* x, const float* rows, const int64_t* row_numbers, int64_t n, int normalize) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && n >= 0 && (n == 0 || (rows && row_numbers)), "vq_index_update_rows: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(x->mu);
+    // the reference assigns in call order (hnsw.py:160), so the LAST update of a row is the one that stays: keep that one
+    std::vector<int64_t> keep;            // indices into rows / row_numbers, in order
+    {
+        std::vector<std::pair<int64_t, int64_t>> last;          // (row number, index of its last update)
+        last.reserve((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            VQ_CHECK(row_numbers[i] >= 0 && row_numbers[i] < x->size, "vq_index_update_rows: row %lld outside [0, %lld)",
+                     (long long)row_numbers[i], (long long)x->size);
+            last.emplace_back(row_numbers[i], i);
+        }
+        std::stable_sort(last.begin(), last.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t i = 0; i < last.size(); ++i)
+            if (i + 1 == last.size() || last[i + 1].first != last[i].first) keep.push_back(last[i].second);
+        std::sort(keep.begin(), keep.end());
+    }
+    const int64_t m = (int64_t)keep.size();
+    const int64_t row_bytes = (int64_t)x->dim * 4;
+    VQ_TRY(reserve_buf(x->d_upd, x->upd_cap, m * x->dim + m * 2 + 4));
+    int64_t* d_rn = (int64_t*)(x->d_upd + round_up(m * x->dim, 2));       // 8-byte aligned behind the rows
+    std::vector<int64_t> rn((size_t)m);
+    if (m == n) {
+        VQ_HIP(hipMemcpyAsync(x->d_upd, rows, (size_t)(n * row_bytes), hipMemcpyHostToDevice, x->stream));
+        for (int64_t i = 0; i < m; ++i) rn[(size_t)i] = row_numbers[i];
+    } else {
+        for (int64_t i = 0; i < m; ++i) {
+            VQ_HIP(hipMemcpyAsync(x->d_upd + i * x->dim, rows + keep[(size_t)i] * x->dim, (size_t)row_bytes, hipMemcpyHostToDevice, x->stream));
+            rn[(size_t)i] = row_numbers[keep[(size_t)i]];
+        }
+    }
+    VQ_HIP(hipMemcpyAsync(d_rn, rn.data(), (size_t)m * 8, hipMemcpyHostToDevice, x->stream));
+    {
+        Prof p(x, I_NORMALIZE);
+        if (normalize) {
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3(cdiv(m, NORM_ROWS)), dim3(NORM_ROWS), 0, x->stream, x->d_upd, m, x->dim);
+        } else {          // measured, not trusted (finish_add); the range only widens: a replaced row's old norm stays covered
+            if (!x->d_norm_range) {
+                VQ_HIP(hipMalloc((void**)&x->d_norm_range, 8));
+                const uint32_t init[2] = {0x3f800000u, 0x3f800000u};
+                VQ_HIP(hipMemcpyAsync(x->d_norm_range, init, 8, hipMemcpyHostToDevice, x->stream));
+                VQ_HIP(hipStreamSynchronize(x->stream));
+            }
+            hipLaunchKernelGGL(row_norm_range_kernel, dim3(cdiv(m, 4)), dim3(256), 0, x->stream, x->d_upd, m, x->dim, x->d_norm_range);
+            x->norm_dirty = true;
+        }
+    }
+    {
+        Prof p(x, I_TO_F16);
+        const int64_t count4 = m * x->dim / 4;
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 2048)), dim3(256), 0, x->stream,
+                           x->d_upd, d_rn, m, x->dim, x->rows, x->rows16);
+    }
+    VQ_HIP(hipGetLastError());
+    VQ_TRY(refresh_norm_range(x));
+    VQ_HIP(hipStreamSynchronize(x->stream));      // `rows`, `rn` are the caller's / this frame's
+    return 0;
 }
 
 int vq_index_search_device(vq_index* x, const void* d_queries, int nq, int k, int mode, void* d_ids, void* d_dist) {

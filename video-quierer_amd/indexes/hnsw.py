@@ -105,10 +105,11 @@ class HNSWIndex:
             unit = np.stack([self._unit(v) for v in vs])
             unit = np.ascontiguousarray(unit, dtype=np.float32)
             fresh_rows, fresh_ids = [], []
+            upd_rows, upd_src = [], []                                   # re-added ids: (stored row, batch position), in call order
             seen_now: Dict[Hashable, int] = {}
             for j, nid in enumerate(node_ids[:n]):
                 if nid in self._row_of:
-                    self._overwrite(self._row_of[nid], unit[j])
+                    upd_rows.append(self._row_of[nid]); upd_src.append(j)
                 elif nid in seen_now:                                    # later duplicate wins (dict semantics)
                     fresh_rows[seen_now[nid]] = j
                 else:
@@ -116,6 +117,8 @@ class HNSWIndex:
                     fresh_rows.append(j)
                     fresh_ids.append(nid)
                 self.element_count += 1                                   # reference counts every add (:229)
+            if upd_rows:
+                self._overwrite(upd_rows, unit if len(upd_src) == n else np.ascontiguousarray(unit[upd_src]))
             if fresh_rows:
                 block = unit if len(fresh_rows) == n else np.ascontiguousarray(unit[fresh_rows])
                 _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(block), len(fresh_rows), 0))
@@ -148,13 +151,13 @@ class HNSWIndex:
             if self.entry_point is None and self._ids:
                 self.entry_point = self._ids[0]
 
-    def _overwrite(self, row: int, unit_vec: np.ndarray) -> None:
-        # re-adding an id replaces its vector (dict assignment in the reference, :160); rare → rebuild
-        rows = self._export()
-        rows[row] = unit_vec
-        lib = _lib.load()
-        _lib.check(lib.vq_index_clear(self._h))
-        _lib.check(lib.vq_index_add(self._h, _lib.fptr(rows), rows.shape[0], 0))
+    def _overwrite(self, rows: Sequence[int], unit_vecs: np.ndarray) -> None:
+        """Re-adding an id replaces its vector (a dict assignment in the reference, hnsw.py:160): the stored rows are
+        replaced in place on the device — fp32 master, fp16 scan copy, norm range — in one call; a row named twice
+        keeps its last vector, as sequential assignments would leave it."""
+        rn = np.ascontiguousarray(rows, dtype=np.int64)
+        _lib.check(_lib.load().vq_index_update_rows(self._h, _lib.fptr(unit_vecs), rn.ctypes.data_as(POINTER(ctypes.c_int64)),
+                                                    len(rn), 0))
 
     # -- query --------------------------------------------------------------------
     def _raw_search(self, unit_queries: np.ndarray, k: int):
