@@ -146,11 +146,15 @@ def parse():
                          "sleep, the exchange steps run on CPU tensors (tests/test_distributed_cpu.py)")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="N>1 data-path collectives: libvq_amd's own RCCL calls (vq_comm_*) or torch.distributed")
+    ap.add_argument("--workload", choices=["headline", "config4"], default="headline",
+                    help="headline = configs[1] encode (+ configs[2] search); config4 = configs[3] end to end (4 x 1000 frames -> "
+                         "all-gather -> index -> 1k queries)")
     ap.add_argument("--search-rows", type=int, default=1_000_000)
     ap.add_argument("--search-queries", type=int, default=10_000)
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-preprocess", action="store_true", help="skip the resize leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-frames end-to-end leg (extract -> add_batch -> search)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 50,000-frame configs[1] job after the timed steps")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (~15 s of host work)")
     ap.add_argument("--dtype", default=None,
@@ -235,6 +239,93 @@ def rehearse_cpu(args):
                                      "gathered_rows": int(rows.shape[0]), "merged_ids": int(gid.numel())}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_config4(args, torch, dist, dev, local, rank, world, comm, exchange, backend, cfg, encs, streams, fence, max_over_ranks):
+    """configs[3]: 4 videos x 1000 frames, video v on ranks {2v, 2v+1} at N = 8 (contiguous frame shards at any N) ->
+    encode the shard -> all-gather of the per-shard embeddings (ragged counts; vq_allgather_rows over RCCL when the native
+    exchange is up) -> EVERY rank indexes all 4,000 rows under the caller's string ids (video_search_system.py:164-181)
+    -> 1,000 queries split over the ranks, k = 10.  A step = the whole job; timed --steps times after --warmup."""
+    from video_quierer_amd.distributed import shard_range
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    videos, per, nq, k = 4, 1000, 1000, 10
+    total = videos * per
+    lo, hi = shard_range(total, rank, world)
+    counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    mine = hi - lo
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    frames = torch.randint(0, 255, (mine, cfg.image_size, cfg.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
+    emb = torch.empty((max(counts), cfg.proj_dim), dtype=torch.float32, device=dev)
+    allrows = torch.empty((total, cfg.proj_dim), dtype=torch.float32, device=dev)
+    ids = [f"video{g // per}_{g % per}" for g in range(total)]
+    qlo, qhi = shard_range(nq, rank, world)
+    d_ids = torch.empty((qhi - qlo, k), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((qhi - qlo, k), dtype=torch.float32, device=dev)
+    enc, st = encs[0], streams[0]
+    timing = {}
+
+    def job():
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            for b0 in range(0, mine, BATCH):
+                n = min(BATCH, mine - b0)
+                enc.encode_device(frames[b0:].data_ptr(), n, emb[b0:].data_ptr())
+            if world > 1:
+                if comm is not None:
+                    comm.all_gather_rows(emb.data_ptr(), counts, cfg.proj_dim, allrows.data_ptr(), st.cuda_stream)
+                else:
+                    pad = torch.zeros((world, max(counts), cfg.proj_dim), dtype=torch.float32, device=dev)
+                    dist.all_gather_into_tensor(pad.view(-1, cfg.proj_dim), emb)
+                    off = 0
+                    for r in range(world):
+                        allrows[off:off + counts[r]] = pad[r, :counts[r]]
+                        off += counts[r]
+            else:
+                allrows.copy_(emb[:total])
+        st.synchronize()
+        t1 = time.perf_counter()
+        idx = OptimizedHNSWIndex(dimension=cfg.proj_dim, device=local)
+        idx.set_stream(st.cuda_stream)
+        idx.add_device(allrows.data_ptr(), total, ids, normalize=True)
+        st.synchronize()
+        t2 = time.perf_counter()
+        # queries: noisy copies of stored frames (as scripts/e2e_config4.py), the same on every rank; this rank answers [qlo, qhi)
+        qg = torch.Generator(device=dev)
+        qg.manual_seed(5)
+        pick = torch.randint(0, total, (nq,), device=dev, generator=qg)
+        q = allrows[pick] + 0.05 * torch.randn((nq, cfg.proj_dim), device=dev, generator=qg)
+        q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        with torch.cuda.stream(st):
+            idx.search_device(q[qlo:qhi].data_ptr(), qhi - qlo, k, d_ids.data_ptr(), d_dist.data_ptr())
+        st.synchronize()
+        t4 = time.perf_counter()
+        top1 = float((d_ids[:, 0].long() == pick[qlo:qhi]).float().mean().item())
+        idx.close()
+        timing.update(encode_gather_s=t1 - t0, index_s=t2 - t1, search_s=t4 - t3, top1_is_source_frame=top1)
+        return (t2 - t0), (t4 - t3)
+
+    for _ in range(max(1, args.warmup)):
+        job()
+    fence()
+    ingest, search = [], []
+    for _ in range(max(1, args.steps)):
+        fence()
+        a, b = job()
+        ingest.append(max_over_ranks(a))
+        search.append(max_over_ranks(b))
+    t_ing, t_q = float(np.median(ingest)), float(np.median(search))
+    return {"metric": METRIC, "value": total / t_ing, "unit": "frames/s", "n_gpus": world, "steps": max(1, args.steps),
+            "warmup": max(1, args.warmup), "ms_per_step": 1e3 * (t_ing + t_q), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[3]: 4 videos x 1000 synthetic 224x224 frames in contiguous frame shards (1 video per 2 GPUs at "
+                                   "N = 8) -> ViT-B/32 encode -> all-gather of embeddings -> every rank indexes all 4,000 rows (string ids) "
+                                   "-> 1,000 queries split over ranks, k = 10; device-resident frames",
+                       "frames_per_rank": counts, "queries_per_rank": qhi - qlo, "parallelism": f"dp{world}"},
+            "world": {"size": world, "backend": backend if world > 1 else None, "exchange": exchange},
+            "queries_per_s": nq / t_q, "ingest_s": t_ing, "search_s": t_q, "last_job": timing}
 
 
 def main():
@@ -338,6 +429,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if args.workload == "config4":
+        out = run_config4(args, torch, dist, dev, local, rank, world, comm, exchange, backend, cfg, encs, streams, fence, max_over_ranks)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        for e_ in encs:
+            e_.close()
+        if comm is not None:
+            comm.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     for i in range(args.warmup):
         step(i)
     fence()
@@ -345,7 +449,8 @@ def main():
     for i in range(args.steps):
         step(i)
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    own_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(own_elapsed)
     frames_per_s = world * args.steps * BATCH / elapsed
 
     # one whole configs[1] job per rank: 50,000 frames = 195 batches of 256 + a ragged batch of 80
@@ -364,7 +469,9 @@ def main():
         sustained = {"frames_per_s": world * job / st, "frames_per_gpu": job, "seconds": st,
                      "passes": full + (1 if tail else 0), "ragged_tail_frames": tail}
 
-    ranks_info = [{"rank": rank, "device": local, "name": torch.cuda.get_device_name(local)}]
+    # per-rank rate over the same timed steps (its own clock, before the max over ranks): a straggler shows here
+    ranks_info = [{"rank": rank, "device": local, "name": torch.cuda.get_device_name(local),
+                   "frames_per_s": args.steps * BATCH / own_elapsed}]
     if world > 1:
         box = [None] * world
         dist.all_gather_object(box, ranks_info[0])
@@ -419,7 +526,7 @@ def main():
         # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
         # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/, gfx950 correction applied there)
         traffic, tsrc = None, None
-        for cand in PMC_TRAFFIC_FILES:
+        for cand in (PMC_TRAFFIC_FILES if args.model == "b32" and BATCH == 256 else ()):     # the PMC passes are ViT-B/32, batch 256: null otherwise
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
@@ -543,10 +650,11 @@ def main():
         # CPU baselines for the search leg (rank 0, N=1 only), over the SAME matrix: what a CPU user would run
         # (numpy sgemm brute force, the reference's live path video_search_overhaul.py:54 np.dot + argsort), the exact
         # C checker (fp64-chain dot, OpenMP), and the pure-Python HNSW restatement (what the reference's modular path runs)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and not args.no_cpu_baseline:
             from oracle import hnsw_oracle, knn_oracle
             import random as _random
             host_rows = idx._export()
+            scope = "all" if world == 1 else "rank 0's shard of"      # N > 1: the CPU leg scans one shard, the GPU number is the whole matrix
             ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
             os.environ["OMP_NUM_THREADS"] = str(ncores)
             qs_host = q[:512].cpu().numpy()
@@ -564,15 +672,15 @@ def main():
                 top = np.take_along_axis(part, np.argsort(-np.take_along_axis(sims, part, 0), axis=0), 0)
                 ct = time.perf_counter() - t0
             srch["cpu_baseline"] = {"value": nb / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
-                                    "sample": f"{nb} of the {nq} queries in one numpy fp32 sgemm over all {n_rows} rows + "
+                                    "sample": f"{nb} of the {nq} queries in one numpy fp32 sgemm over {scope} {n_rows} rows + "
                                               f"argpartition top-{k} (brute force as video_search_overhaul.py:54 computes it), {ct:.2f}s",
-                                    "agrees_with_gpu_top1": float(np.mean(top[0] == ids[:nb, 0].cpu().numpy()))}
+                                    "agrees_with_gpu_top1": float(np.mean(top[0] == ids[:nb, 0].cpu().numpy())) if world == 1 else None}
             ncpu_q = 256
             t0 = time.perf_counter()
             knn_oracle.topk(host_rows, qs_host[:ncpu_q], k)
             ct = time.perf_counter() - t0
             srch["cpu_checker"] = {"value": ncpu_q / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
-                                   "sample": f"{ncpu_q} queries, exact top-{k} over all {n_rows} rows, C oracle "
+                                   "sample": f"{ncpu_q} queries, exact top-{k} over {scope} {n_rows} rows, C oracle "
                                              f"(oracle/knn_oracle.c, fp64-chain dot, OpenMP) - the parity checker, {ct:.2f}s"}
             hn = 2000
             _random.seed(0)
@@ -633,8 +741,41 @@ def main():
         del src, dst
         pre.close()
 
+    # ---- the product path end to end, PCIe and host staging included (never `value`): host frame
+    # dicts as frame_extractor.py yields them -> FeatureExtractor.extract_from_video_frames (pipelined ingest, two handles)
+    # -> OptimizedHNSWIndex.add_batch (row-wise numpy normalisation as hnsw.py:157, one device append) -> one search_batch ----
+    if rank == 0 and world == 1 and args.model == "b32" and not args.no_e2e:
+        from video_quierer_amd.core.feature_extractor import FeatureExtractor
+        hrng = np.random.default_rng(0)
+        distinct = [hrng.integers(0, 255, (224, 224, 3), dtype=np.uint8) for _ in range(1024)]
+        fds = [{"frame": f, "frame_number": i, "timestamp": i / 30.0} for i, f in enumerate(distinct)] * 8      # 8,192 host frames
+        fx = FeatureExtractor(model_name="seed:1234", device=f"cuda:{local}", batch_size=32, device_batch=BATCH, compute_dtype=args.dtype)
+        fx.extract_from_video_frames(fds[:2048])                        # warm-up: staging buffers, both handles
+        best = None
+        for _ in range(2):
+            eidx = OptimizedHNSWIndex(dimension=cfg.proj_dim, device=local)
+            t0 = time.perf_counter()
+            feats = fx.extract_from_video_frames(fds)
+            t1 = time.perf_counter()
+            eidx.add_batch([o["features"] for o in feats], list(range(len(feats))))
+            t2 = time.perf_counter()
+            res = eidx.search_batch([o["features"] for o in feats[:64]], 10)
+            t3 = time.perf_counter()
+            assert len(res) == 64 and res[0][0]["distance"] <= 1e-6        # a stored frame finds itself
+            eidx.close()
+            cur = {"frames": len(fds), "extract_s": t1 - t0, "add_batch_s": t2 - t1, "search_64q_s": t3 - t2,
+                   "extract_frames_per_s": len(fds) / (t1 - t0), "frames_per_s": len(fds) / (t3 - t0)}
+            if best is None or cur["frames_per_s"] > best["frames_per_s"]:
+                best = cur
+        best["path"] = ("host uint8 frame dicts -> FeatureExtractor.extract_from_video_frames (2 ingest handles, pinned staging, H2D) -> "
+                        "OptimizedHNSWIndex.add_batch -> search_batch(64 queries, k=10); best of 2 passes")
+        out["e2e_host"] = best
+        out["e2e_host_frames_per_s"] = best["frames_per_s"]
+        fx.thread_pool.shutdown()
+        del fx, fds, distinct
+
     # ---- CPU baseline: the fp32 oracle (a port of the reference's CPU path) on a bounded sample ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import clip_vit_oracle
         # the GPU box exposes all host cores but grants a one-GPU job a share of 16: more threads than
         # that only oversubscribe (a 256-thread run measured 0.44 frames/s)
@@ -654,12 +795,13 @@ def main():
                                          f"(oracle/clip_vit_oracle.py), preprocessing included, {ct:.2f}s"}
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     for e_ in encs:
         e_.close()
     if comm is not None:
         comm.close()
     if world > 1:
+        dist.barrier()                 # rank 0 arrives last (its CPU baselines); nobody tears the group down under it
         dist.destroy_process_group()
 
 

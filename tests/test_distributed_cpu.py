@@ -98,3 +98,32 @@ def test_bench_launches_its_own_ranks_when_typed_bare():
     # a rank that dies takes the exit code with it and no result line is invented
     p = subprocess.run(cmd, env=dict(env, VQ_BENCH_REHEARSE_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+def test_bench_relaunches_with_the_torch_exchange_when_the_native_bring_up_fails_or_hangs():
+    """N > 1 with the native exchange: each rank is a supervisor (never on the GPU) + a child.  A child whose native
+    communicator cannot be brought up — a clean failure on one rank, or a bring-up that never returns within its deadline —
+    leaves with bench.RELAUNCH_CODE on EVERY rank, and each supervisor starts a fresh child with --exchange torch on a new
+    rendezvous port; the one result line says which path ran.  Rehearsed over gloo with a stand-in communicator."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-cpu"]
+
+    def run(extra):
+        p = subprocess.run(cmd, env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        return json.loads(lines[0]), p.stderr
+
+    out, _ = run({})
+    assert "stand-in" in out["world"]["exchange"]                                # the native path came up: no relaunch
+    out, err = run({"VQ_BENCH_FAKE_NATIVE_FAIL": "1"})                            # rank 1 fails cleanly -> everyone leaves -> torch
+    assert out["world"]["exchange"].startswith("torch.distributed") and "relaunched" in out["world"]["exchange"]
+    assert "bring-up failed" in err and out["config"]["gathered_rows"] == 2 * 256
+    out, err = run({"VQ_BENCH_FAKE_NATIVE_HANG": "0", "VQ_BENCH_COMM_DEADLINE": "4"})   # rank 0 never returns -> deadline -> torch
+    assert "relaunched" in out["world"]["exchange"] and "still not done" in err
+    # asked for the torch exchange from the start: no supervisor, no bring-up
+    p = subprocess.run(cmd + ["--exchange", "torch"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "relaunched" not in p.stdout

@@ -1,0 +1,299 @@
+// Fourth-generation batch scan: scan4_f16_top2_kernel (knn_scan_deep.h) with the top-2 fold taken OUT of the row-tile
+// boundary and spread behind the MFMA clusters that follow it.
+//
+// What scan4 paid (two geometries of one binary): a K-tile costs 2.58k cycles and a row tile carries 9.7k cycles
+// of fixed cost — a third of the 512-d tile.  That fixed part was the fold: per lane 128 scores x {and, or, med3, max, clear}
+// = 640 vector instructions in two bursts (behind phase 4 of a row tile's last K-tile and phase 1 of the next one), each
+// burst issued by a lone wave at one instruction per 4 cycles while its partner wave and the other wave group sat at the
+// barrier — and the two wave groups run one barrier apart, so their bursts came one after the other.
+//
+// Here, per score: v_and_or_b32 (index bits in), v_med3_f32 (second key), v_med3_f32 against a large finite constant
+// (first key: a max the compiler cannot fold back into the canonicalising form) = 3 instructions, and NO clear: the first
+// K-tile of a row tile starts its accumulators from the MFMA's C = 0 operand.  A finished quadrant's accumulators stay
+// untouched until that quadrant's own cluster of the next row tile's first K-tile, i.e. for the three clusters in between;
+// its 96 fold instructions are dealt over those clusters in units of one 16-row block (24 instructions), 2 or 3 blocks per
+// cluster, and interleaved with the cluster's 16 MFMAs (sched_group_barrier: one MFMA, then the cluster's share of vector
+// instructions).  An MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants), so
+// four or five 4-cycle instructions per MFMA stretch such a cluster from 256 to ~400 cycles — on six of a row tile's
+// 32 clusters — instead of adding two ~1,500-cycle bursts per wave group.
+//
+//   cluster (phase)            multiplies     folds (quadrant: 16-row blocks)
+//   last K-tile, phase 2       (0,1)          (0,0): 0 1 2
+//   last K-tile, phase 3       (1,1)          (0,0): 3      (0,1): 0 1
+//   last K-tile, phase 4       (1,0)          (0,1): 2 3
+//   first K-tile, phase 1      (0,0) C = 0    (1,1): 0 1 2
+//   first K-tile, phase 2      (0,1) C = 0    (1,1): 3      (1,0): 0 1
+//   first K-tile, phase 3      (1,1) C = 0    (1,0): 2 3
+//   first K-tile, phase 4      (1,0) C = 0    -
+// Every fold reads a quadrant after its last MFMA of the row tile and before its first MFMA of the next (program order of
+// one wave: no cross-wave hazard).  The last row tile of the range is folded after the loop.  Ragged tiles (the matrix's last
+// range only) take the same schedule with the row mask compiled in, behind a wave-uniform branch.
+//
+// Staging, LDS image, key layout, streams: scan4's.  Results are bit-identical to scan4's keys.
+#pragma once
+#include "vq_common.h"
+#include "gemm_mfma.h"
+#include "gemm_mfma256.h"
+#include "knn_scan_f16.h"
+#include "knn_scan_deep.h"
+
+namespace vq {
+
+// fold blocks dealt to one cluster: N of {query column mi (0..7), matrix-column half hn (0..1)}
+template <int N_, int M0 = 0, int H0 = 0, int M1 = 0, int H1 = 0, int M2 = 0, int H2 = 0>
+struct FoldSpec {
+    static constexpr int N = N_;
+    static constexpr int mi(int s) { return s == 0 ? M0 : s == 1 ? M1 : M2; }
+    static constexpr int hn(int s) { return s == 0 ? H0 : s == 1 ? H1 : H2; }
+};
+
+template <int DIAG /* 0 = product; diagnostic builds: 1 = no fold at all (keys invalid), 2 = fold not interleaved (after the cluster) */>
+__global__ __launch_bounds__(G2_THREADS, 2)
+void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
+                           int dim, int64_t n_valid, int q_tiles, int n_ranges, int range_groups, int64_t q_pad,
+                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/) {
+    typedef mfma_op<true> op;
+    typedef op::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = wg >> 5, inner = wg & 31;
+    const int rg = blk % range_groups, qg = blk / range_groups;
+    const int range = rg * 4 + (inner >> 3);
+    const int qtile = qg * 8 + (inner & 7);
+    if (range >= n_ranges || qtile >= q_tiles) return;   // whole workgroup leaves before any barrier
+    const int m0 = qtile * SCAN2_QT;
+    const int64_t n0 = (int64_t)range * SCAN2_RANGE;
+
+    // ---- LDS-DMA (scan4): 4 lane-offset registers, unit / piece / K / row-tile offsets scalar ----
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int arow_w = (wave >> 2) * 128 + (wave & 3) * 16, wrow_w = (wave >> 1) * 64 + (wave & 1) * 16;
+    const int ar = arow_w + srow, wrw = wrow_w + srow;
+    const int a_v0 = (ar * dim + (sslot ^ ((ar >> 1) & 7)) * 8) * 2, a_v1 = a_v0 ^ 64;
+    const int w_v0 = (wrw * dim + (sslot ^ ((wrw >> 1) & 7)) * 8) * 2, w_v1 = w_v0 ^ 64;
+    const int a_dst0 = arow_w * 128, w_dst0 = 2 * G2_HALF + wrow_w * 128;
+    const int row8 = 8 * dim * 2;
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(Q16 + (size_t)m0 * dim), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)(X16 + (size_t)n0 * dim), 0, 0x7fffffff, 0x00020000);
+
+    const int nk = dim / G2_BK;                          // K-tiles per row tile (even)
+    const int total = 8 * nk;
+    const int tile_bytes = 256 * dim * 2;
+
+    auto stage_a = [&](int buf, int hm, int kk) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + a_dst0 + hm * (64 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(kk * (G2_BK * 2) + hm * 8 * row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base), 16, a_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + 1024), 16, a_v1, soff + row8, 0, 0);
+    };
+    auto stage_w = [&](int buf, int hn, int t, int kk) __attribute__((always_inline)) {
+        char* base = smem + buf * G2_BUF + w_dst0 + hn * (32 * 128);
+        const int soff = __builtin_amdgcn_readfirstlane(t * tile_bytes + kk * (G2_BK * 2) + hn * 4 * row8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + row8, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fx = (frow >> 1) & 7;
+    const int slot[2] = {((0 + fgrp) ^ fx) * 16, ((4 + fgrp) ^ fx) * 16};
+    const int a_base = wr * G2_HALF + frow * 128;
+    const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;
+
+    f32x4 acc[8][4];                     // NOT initialised: a row tile's first K-tile multiplies into C = 0
+    frag af[4][2], wf[2][2][2];
+    const float NEG = -__builtin_inff();
+    const float MASKED = -3.0e38f;       // finite: see scan_f16_top2_kernel
+    // first-key update as med3(first, key, BIG): = max(first, key) for every key below BIG, and not foldable into fmaxf (whose
+    // IEEE-mode lowering canonicalises both operands first: two extra instructions per score)
+    float BIG = 3.0e38f;
+    uint32_t keep_mask = ~127u;          // in a VGPR: v_and_or_b32 then takes (score, mask, index) with the index as its one scalar
+    asm volatile("" : "+v"(BIG), "+v"(keep_mask));
+    float2* mm = (float2*)(smem + G2_LDS_BYTES) + wave * (8 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm[i * 64] = float2{NEG, NEG};
+
+    auto load_a = [&](const char* buf, int hm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[i][ks] = *(const frag*)(buf + a_base + (hm * 4 + i) * 2048 + slot[ks]);
+    };
+    auto load_w = [&](const char* buf, int hn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[hn][j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
+    };
+    // one 16-row block (mi) x one 32-column half (hn) of a finished row tile -> running top-2 of the lane's query column mi
+    auto fold_block = [&](auto ragged_tag, int mi, int hn, int t, float2& p) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        const int row_lane = t * 256 + wc * 64 + 4 * fgrp;
+        const int rows_left = (int)min((int64_t)SCAN2_RANGE, n_valid - n0);   // RAGGED only
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ni = hn * 2 + j;
+                float v = acc[mi][ni][r];
+                if constexpr (RAGGED) { if (row_lane + ni * 16 + r >= rows_left) v = MASKED; }
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane(t * 16 + ni * 4 + r);
+                const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & keep_mask) | idx);
+                p.y = __builtin_amdgcn_fmed3f(p.x, p.y, kf);
+                p.x = __builtin_amdgcn_fmed3f(p.x, kf, BIG);
+            }
+    };
+    auto barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    // A cluster: 16 MFMAs of quadrant (hm, hn), C = 0 on the first K-tile of a row tile, with the fold blocks of `spec`
+    // (row tile ft) dealt between them.
+    auto cluster = [&](auto first_tag, auto ragged_tag, int hm, int hn, auto spec, int ft, bool do_fold) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        typedef decltype(spec) S;
+        const bool folding = DIAG != 1 && S::N > 0 && do_fold;       // wave-uniform
+        auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4& c = acc[hm * 4 + i][hn * 2 + j];
+                        if (FIRST && ks == 0) c = op::run(wf[hn][j][ks], af[i][ks], f32x4{0.f, 0.f, 0.f, 0.f});
+                        else                  c = op::run(wf[hn][j][ks], af[i][ks], c);
+                    }
+        };
+        __builtin_amdgcn_s_setprio(1);
+        if (!folding) {
+            mfmas();
+        } else {
+            // (a column's two halves hn = 0, 1 go through the same running pair: the schedule never deals both to one cluster)
+            float2 p[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) if (s < S::N) p[s] = mm[S::mi(s) * 64];
+            if constexpr (DIAG == 2) mfmas();
+#pragma unroll
+            for (int s = 0; s < 3; ++s) if (s < S::N) fold_block(ragged_tag, S::mi(s), S::hn(s), ft, p[s]);
+            if constexpr (DIAG != 2) mfmas();
+#pragma unroll
+            for (int s = 0; s < 3; ++s) if (s < S::N) mm[S::mi(s) * 64] = p[s];
+            if constexpr (DIAG != 2) {
+                // 16 x {1 MFMA, the cluster's share of the fold's vector instructions}: 24 per block
+                constexpr int per = (S::N * 24 + 15) / 16;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // One K-tile.  FIRST: first K-tile of a row tile (accumulators start from C = 0; carries the second half of the previous
+    // row tile's fold when there is one: fold_prev).  LAST: last K-tile of a row tile (carries the first half of this tile's fold).
+    auto tile = [&](auto first_tag, auto last_tag, auto ragged_tag, int kt, int bufi, bool fold_prev, int t, int kk) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const char* buf = smem + bufi * G2_BUF;
+        const bool next = kt + 1 < total, next2 = kt + 2 < total;
+        const int kk1 = kk + 1 == nk ? 0 : kk + 1, t1 = kk + 1 == nk ? t + 1 : t;
+        const int kk2 = kk1 + 1 == nk ? 0 : kk1 + 1, t2 = kk1 + 1 == nk ? t1 + 1 : t1;
+        // phase 1: quadrant (0,0)
+        load_a(buf, 0); load_w(buf, 0);
+        if (next) { stage_w(bufi ^ 1, 1, t1, kk1); VQ_VMCNT(8); }
+        else      { VQ_VMCNT(2); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cluster(first_tag, ragged_tag, 0, 0, FoldSpec<3, 4, 1, 5, 1, 6, 1>{}, t - 1, fold_prev);                 // (1,1): 0 1 2
+        barrier();
+        // phase 2: quadrant (0,1)
+        load_w(buf, 1);
+        if (next) { stage_a(bufi ^ 1, 1, kk1); VQ_VMCNT(8); }
+        else      { VQ_VMCNT(0); }
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (LAST) cluster(first_tag, ragged_tag, 0, 1, FoldSpec<3, 0, 0, 1, 0, 2, 0>{}, t, true);          // (0,0): 0 1 2
+        else                cluster(first_tag, ragged_tag, 0, 1, FoldSpec<3, 7, 1, 4, 0, 5, 0>{}, t - 1, fold_prev); // (1,1): 3   (1,0): 0 1
+        barrier();
+        // phase 3: quadrant (1,1)
+        load_a(buf, 1);
+        if (next2) stage_a(bufi, 0, kk2);
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (LAST) cluster(first_tag, ragged_tag, 1, 1, FoldSpec<3, 3, 0, 0, 1, 1, 1>{}, t, true);          // (0,0): 3   (0,1): 0 1
+        else                cluster(first_tag, ragged_tag, 1, 1, FoldSpec<2, 6, 0, 7, 0>{}, t - 1, fold_prev);       // (1,0): 2 3
+        barrier();
+        // phase 4: quadrant (1,0): no fragment reads
+        if (next2)     { stage_w(bufi, 0, t2, kk2); VQ_VMCNT(8); }
+        else if (next) { VQ_VMCNT(4); }
+        barrier();
+        if constexpr (LAST) cluster(first_tag, ragged_tag, 1, 0, FoldSpec<2, 2, 1, 3, 1>{}, t, true);                // (0,1): 2 3
+        else                cluster(first_tag, ragged_tag, 1, 0, FoldSpec<0>{}, t, false);
+        barrier();
+    };
+
+    // ---- prologue: tile 0 complete + A0, W0 of tile 1 in flight; A0(0), W0(0) landed ----
+    stage_a(0, 0, 0); stage_w(0, 0, 0, 0); stage_w(0, 1, 0, 0); stage_a(0, 1, 0);
+    stage_a(1, 0, 1); stage_w(1, 0, 0, 1);               // nk >= 2: K-tile 1 is still in row tile 0
+    VQ_VMCNT(8);
+    barrier();
+
+    // ragged = some row of this range lies beyond the matrix: only the matrix's last range (wave-uniform; the fold of EVERY
+    // tile of that range then carries the row mask, which costs that one range a few instructions per score)
+    const bool ragged = n0 + SCAN2_RANGE > n_valid;
+    if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
+    int kk = 0, t = 0;
+    const std::true_type T{}; const std::false_type F{};
+    for (int kt = 0; kt < total; kt += 2) {              // nk is even: a row tile starts on an even kt and ends on an odd one
+        const bool first = kk == 0, last = kk + 2 == nk;
+        if (__builtin_expect(ragged, 0)) {
+            if (first) tile(T, F, T, kt, 0, t > 0, t, kk); else tile(F, F, T, kt, 0, false, t, kk);
+            ++kk;
+            if (last) tile(F, T, T, kt + 1, 1, false, t, kk); else tile(F, F, T, kt + 1, 1, false, t, kk);
+        } else {
+            if (first) tile(T, F, F, kt, 0, t > 0, t, kk); else tile(F, F, F, kt, 0, false, t, kk);
+            ++kk;
+            if (last) tile(F, T, F, kt + 1, 1, false, t, kk); else tile(F, F, F, kt + 1, 1, false, t, kk);
+        }
+        if (++kk == nk) { kk = 0; ++t; }
+    }
+    // the last row tile's second half: nothing left to hide it behind
+    if (DIAG != 1) {
+        auto tail = [&](auto ragged_tag) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                // quadrants (1,1) then (1,0)
+                const int hn = q == 0 ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float2 p = mm[(4 + i) * 64];
+                    fold_block(ragged_tag, 4 + i, hn, 7, p);
+                    mm[(4 + i) * 64] = p;
+                }
+            }
+        };
+        if (ragged) tail(T); else tail(F);
+    }
+    if (wr == 0) barrier();               // every wave executes the same number of barriers
+#undef VQ_VMCNT
+
+    const int64_t stream = (int64_t)range * 16 + wc * 4 + fgrp;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int q = m0 + wr * 128 + mi * 16 + frow;
+        const float2 p = mm[mi * 64];
+        *(uint2*)(keys + batch_key_index(stream, q, (int64_t)n_ranges * 16)) = uint2{__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y)};
+    }
+}
+
+}  // namespace vq
