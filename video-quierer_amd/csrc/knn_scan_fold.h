@@ -8,10 +8,11 @@
 // barrier — and the two wave groups run one barrier apart, so their bursts came one after the other.
 //
 // Here, per score: v_and_or_b32 (index bits in), v_med3_f32 (second key), v_med3_f32 against a large finite constant
-// (first key: a max the compiler cannot fold back into the canonicalising form) = 3 instructions, and NO clear: the first
-// K-tile of a row tile starts its accumulators from the MFMA's C = 0 operand.  A finished quadrant's accumulators stay
+// (first key: a max the compiler cannot fold back into the canonicalising form) and the clear = 4 instructions.  (Starting a
+// row tile from the MFMA's C = 0 operand instead of clearing needs a second copy of every K-tile body; with it the register
+// allocator spilled ~100 registers across the merge points, so the clear stays.)  A finished quadrant's accumulators stay
 // untouched until that quadrant's own cluster of the next row tile's first K-tile, i.e. for the three clusters in between;
-// its 96 fold instructions are dealt over those clusters in units of one 16-row block (24 instructions), 2 or 3 blocks per
+// its 128 fold instructions are dealt over those clusters in units of one 16-row block (32 instructions), 2 or 3 blocks per
 // cluster, and interleaved with the cluster's 16 MFMAs (sched_group_barrier: one MFMA, then the cluster's share of vector
 // instructions).  An MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants), so
 // four or five 4-cycle instructions per MFMA stretch such a cluster from 256 to ~400 cycles — on six of a row tile's
@@ -21,10 +22,10 @@
 //   last K-tile, phase 2       (0,1)          (0,0): 0 1 2
 //   last K-tile, phase 3       (1,1)          (0,0): 3      (0,1): 0 1
 //   last K-tile, phase 4       (1,0)          (0,1): 2 3
-//   first K-tile, phase 1      (0,0) C = 0    (1,1): 0 1 2
-//   first K-tile, phase 2      (0,1) C = 0    (1,1): 3      (1,0): 0 1
-//   first K-tile, phase 3      (1,1) C = 0    (1,0): 2 3
-//   first K-tile, phase 4      (1,0) C = 0    -
+//   first K-tile, phase 1      (0,0)          (1,1): 0 1 2
+//   first K-tile, phase 2      (0,1)          (1,1): 3      (1,0): 0 1
+//   first K-tile, phase 3      (1,1)          (1,0): 2 3
+//   first K-tile, phase 4      (1,0)          -
 // Every fold reads a quadrant after its last MFMA of the row tile and before its first MFMA of the next (program order of
 // one wave: no cross-wave hazard).  The last row tile of the range is folded after the loop.  Ragged tiles (the matrix's last
 // range only) take the same schedule with the row mask compiled in, behind a wave-uniform branch.
@@ -104,10 +105,14 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     const int a_base = wr * G2_HALF + frow * 128;
     const int w_base = 2 * G2_HALF + (wc >> 1) * G2_HALF + ((wc & 1) * 64 + frow) * 128;
 
-    f32x4 acc[8][4];                     // NOT initialised: a row tile's first K-tile multiplies into C = 0
-    frag af[4][2], wf[2][2][2];
     const float NEG = -__builtin_inff();
     const float MASKED = -3.0e38f;       // finite: see scan_f16_top2_kernel
+    f32x4 acc[8][4];                     // rows 64..127 of the wave's queries start at MASKED: see the main loop
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float z = (DIAG != 1 && i >= 4) ? MASKED : 0.f; acc[i][j] = f32x4{z, z, z, z}; }
+    frag af[4][2], wf[2][2][2];
     // first-key update as med3(first, key, BIG): = max(first, key) for every key below BIG, and not foldable into fmaxf (whose
     // IEEE-mode lowering canonicalises both operands first: two extra instructions per score)
     float BIG = 3.0e38f;
@@ -116,6 +121,8 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     float2* mm = (float2*)(smem + G2_LDS_BYTES) + wave * (8 * 64) + lane;
 #pragma unroll
     for (int i = 0; i < 8; ++i) mm[i * 64] = float2{NEG, NEG};
+    // ragged = some row of this range lies beyond the matrix: only the matrix's last range (wave-uniform)
+    const bool ragged = n0 + SCAN2_RANGE > n_valid;
 
     auto load_a = [&](const char* buf, int hm) __attribute__((always_inline)) {
 #pragma unroll
@@ -131,23 +138,25 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
             for (int ks = 0; ks < 2; ++ks)
                 wf[hn][j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
     };
-    // one 16-row block (mi) x one 32-column half (hn) of a finished row tile -> running top-2 of the lane's query column mi
-    auto fold_block = [&](auto ragged_tag, int mi, int hn, int t, float2& p) __attribute__((always_inline)) {
+    // one score of a finished row tile -> the running top-2 of its query column; clears it.  e = j*4 + r inside the block
+    // (query column mi, matrix-row half hn)
+    auto fold_score = [&](auto ragged_tag, int mi, int hn, int e, int t, float2& p) __attribute__((always_inline)) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        const int row_lane = t * 256 + wc * 64 + 4 * fgrp;
-        const int rows_left = (int)min((int64_t)SCAN2_RANGE, n_valid - n0);   // RAGGED only
+        const int ni = hn * 2 + (e >> 2), r = e & 3;
+        float v = acc[mi][ni][r];
+        if constexpr (RAGGED) {
+            const int rows_left = (int)min((int64_t)SCAN2_RANGE, n_valid - n0);
+            if (t * 256 + wc * 64 + 4 * fgrp + ni * 16 + r >= rows_left) v = MASKED;
+        }
+        const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((t * 16 + ni * 4 + r) & 127);     // & 127: t = -1 on row tile 0's first K-tile
+        const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & keep_mask) | idx);
+        p.y = __builtin_amdgcn_fmed3f(p.x, p.y, kf);
+        p.x = __builtin_amdgcn_fmed3f(p.x, kf, BIG);
+        acc[mi][ni][r] = 0.f;
+    };
+    auto fold_block = [&](auto ragged_tag, int mi, int hn, int t, float2& p) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ni = hn * 2 + j;
-                float v = acc[mi][ni][r];
-                if constexpr (RAGGED) { if (row_lane + ni * 16 + r >= rows_left) v = MASKED; }
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane(t * 16 + ni * 4 + r);
-                const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & keep_mask) | idx);
-                p.y = __builtin_amdgcn_fmed3f(p.x, p.y, kf);
-                p.x = __builtin_amdgcn_fmed3f(p.x, kf, BIG);
-            }
+        for (int e = 0; e < 8; ++e) fold_score(ragged_tag, mi, hn, e, t, p);
     };
     auto barrier = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
@@ -156,55 +165,64 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     };
 #define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-    // A cluster: 16 MFMAs of quadrant (hm, hn), C = 0 on the first K-tile of a row tile, with the fold blocks of `spec`
-    // (row tile ft) dealt between them.
-    auto cluster = [&](auto first_tag, auto ragged_tag, int hm, int hn, auto spec, int ft, bool do_fold) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    auto mfmas = [&](int hm, int hn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+    };
+    // 16 MFMAs of quadrant (hm, hn) with the fold blocks of `spec` (row tile ft) dealt between them BY HAND: after MFMA m come
+    // the scores [m * Q / 16, (m + 1) * Q / 16) of the cluster's Q = 8 N (one or two: 4 or 8 vector instructions in a 16-cycle
+    // MFMA shadow of which the MFMA itself holds the issue port for 8), pinned by sched_barrier(0) on both sides.  One block's
+    // running pair is live at a time: it is read from LDS one MFMA before its first score and written back after its last.
+    // (Left to sched_group_barrier the same work kept all three pairs and their temporaries live across the cluster: 59 spills.)
+    auto cluster_fold = [&](auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
         typedef decltype(spec) S;
-        const bool folding = DIAG != 1 && S::N > 0 && do_fold;       // wave-uniform
-        auto mfmas = [&]() __attribute__((always_inline)) {
+        constexpr int Q = S::N * 8;
+        float2 p[3];
+        p[0] = mm[S::mi(0) * 64];
+        if constexpr (DIAG == 2) {
+            mfmas(hm, hn);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4& c = acc[hm * 4 + i][hn * 2 + j];
-                        if (FIRST && ks == 0) c = op::run(wf[hn][j][ks], af[i][ks], f32x4{0.f, 0.f, 0.f, 0.f});
-                        else                  c = op::run(wf[hn][j][ks], af[i][ks], c);
-                    }
-        };
-        __builtin_amdgcn_s_setprio(1);
-        if (!folding) {
-            mfmas();
-        } else {
-            // (a column's two halves hn = 0, 1 go through the same running pair: the schedule never deals both to one cluster)
-            float2 p[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) if (s < S::N) p[s] = mm[S::mi(s) * 64];
-            if constexpr (DIAG == 2) mfmas();
-#pragma unroll
-            for (int s = 0; s < 3; ++s) if (s < S::N) fold_block(ragged_tag, S::mi(s), S::hn(s), ft, p[s]);
-            if constexpr (DIAG != 2) mfmas();
-#pragma unroll
-            for (int s = 0; s < 3; ++s) if (s < S::N) mm[S::mi(s) * 64] = p[s];
-            if constexpr (DIAG != 2) {
-                // 16 x {1 MFMA, the cluster's share of the fold's vector instructions}: 24 per block
-                constexpr int per = (S::N * 24 + 15) / 16;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
-                }
-            }
+            for (int s = 0; s < 3; ++s) if (s < S::N) { if (s) p[s] = mm[S::mi(s) * 64]; fold_block(ragged_tag, S::mi(s), S::hn(s), ft, p[s]); mm[S::mi(s) * 64] = p[s]; }
+            return;
         }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int ks = m >> 3, i = (m >> 1) & 3, j = m & 1;
+            acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int q0 = m * Q / 16, q1 = (m + 1) * Q / 16;
+            // the pair of the block that starts in the NEXT gap
+            const int qn = (m + 2) * Q / 16 < Q ? (m + 2) * Q / 16 : Q;
+#pragma unroll
+            for (int q = q1; q < qn; ++q) if ((q & 7) == 0 && (q >> 3) > 0 && (q >> 3) < S::N) p[q >> 3] = mm[S::mi(q >> 3) * 64];
+#pragma unroll
+            for (int q = q0; q < q1; ++q) {
+                const int sblk = q >> 3, e = q & 7;
+                fold_score(ragged_tag, S::mi(sblk), S::hn(sblk), e, ft, p[sblk]);
+                if (e == 7) mm[S::mi(sblk) * 64] = p[sblk];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto cluster = [&](auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
+        typedef decltype(spec) S;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (DIAG == 1 || S::N == 0) mfmas(hm, hn);
+        else cluster_fold(ragged_tag, hm, hn, spec, ft);
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // One K-tile.  FIRST: first K-tile of a row tile (accumulators start from C = 0; carries the second half of the previous
-    // row tile's fold when there is one: fold_prev).  LAST: last K-tile of a row tile (carries the first half of this tile's fold).
-    auto tile = [&](auto first_tag, auto last_tag, auto ragged_tag, int kt, int bufi, bool fold_prev, int t, int kk) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_tag)::value;
+    // One K-tile.  KIND 0: inside a row tile (no fold); 1: first K-tile of a row tile (carries the second half of the previous row
+    // tile's fold — for t = 0 that folds the kernel's initial accumulators, see below); 2: last K-tile of a row tile (first half of
+    // this tile's fold).  Every variant is straight-line code around its MFMAs: conditional copies of a cluster meet in phi
+    // nodes over the 32 accumulators they write, and the register allocator then spills (measured: 15-77 registers).
+    auto tile = [&](auto kind_tag, auto ragged_tag, int kt, int bufi, int t, int kk) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_tag)::value;
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < total, next2 = kt + 2 < total;
         const int kk1 = kk + 1 == nk ? 0 : kk + 1, t1 = kk + 1 == nk ? t + 1 : t;
@@ -215,7 +233,8 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         else      { VQ_VMCNT(2); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cluster(first_tag, ragged_tag, 0, 0, FoldSpec<3, 4, 1, 5, 1, 6, 1>{}, t - 1, fold_prev);                 // (1,1): 0 1 2
+        if constexpr (KIND == 1) cluster(ragged_tag, 0, 0, FoldSpec<3, 4, 1, 5, 1, 6, 1>{}, t - 1);       // (1,1): 0 1 2
+        else                     cluster(ragged_tag, 0, 0, FoldSpec<0>{}, t);
         barrier();
         // phase 2: quadrant (0,1)
         load_w(buf, 1);
@@ -223,23 +242,25 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         else      { VQ_VMCNT(0); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (LAST) cluster(first_tag, ragged_tag, 0, 1, FoldSpec<3, 0, 0, 1, 0, 2, 0>{}, t, true);          // (0,0): 0 1 2
-        else                cluster(first_tag, ragged_tag, 0, 1, FoldSpec<3, 7, 1, 4, 0, 5, 0>{}, t - 1, fold_prev); // (1,1): 3   (1,0): 0 1
+        if constexpr (KIND == 2)      cluster(ragged_tag, 0, 1, FoldSpec<3, 0, 0, 1, 0, 2, 0>{}, t);      // (0,0): 0 1 2
+        else if constexpr (KIND == 1) cluster(ragged_tag, 0, 1, FoldSpec<3, 7, 1, 4, 0, 5, 0>{}, t - 1);  // (1,1): 3   (1,0): 0 1
+        else                          cluster(ragged_tag, 0, 1, FoldSpec<0>{}, t);
         barrier();
         // phase 3: quadrant (1,1)
         load_a(buf, 1);
         if (next2) stage_a(bufi, 0, kk2);
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (LAST) cluster(first_tag, ragged_tag, 1, 1, FoldSpec<3, 3, 0, 0, 1, 1, 1>{}, t, true);          // (0,0): 3   (0,1): 0 1
-        else                cluster(first_tag, ragged_tag, 1, 1, FoldSpec<2, 6, 0, 7, 0>{}, t - 1, fold_prev);       // (1,0): 2 3
+        if constexpr (KIND == 2)      cluster(ragged_tag, 1, 1, FoldSpec<3, 3, 0, 0, 1, 1, 1>{}, t);      // (0,0): 3   (0,1): 0 1
+        else if constexpr (KIND == 1) cluster(ragged_tag, 1, 1, FoldSpec<2, 6, 0, 7, 0>{}, t - 1);        // (1,0): 2 3
+        else                          cluster(ragged_tag, 1, 1, FoldSpec<0>{}, t);
         barrier();
         // phase 4: quadrant (1,0): no fragment reads
         if (next2)     { stage_w(bufi, 0, t2, kk2); VQ_VMCNT(8); }
         else if (next) { VQ_VMCNT(4); }
         barrier();
-        if constexpr (LAST) cluster(first_tag, ragged_tag, 1, 0, FoldSpec<2, 2, 1, 3, 1>{}, t, true);                // (0,1): 2 3
-        else                cluster(first_tag, ragged_tag, 1, 0, FoldSpec<0>{}, t, false);
+        if constexpr (KIND == 2) cluster(ragged_tag, 1, 0, FoldSpec<2, 2, 1, 3, 1>{}, t);                 // (0,1): 2 3
+        else                     cluster(ragged_tag, 1, 0, FoldSpec<0>{}, t);
         barrier();
     };
 
@@ -249,28 +270,24 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     VQ_VMCNT(8);
     barrier();
 
-    // ragged = some row of this range lies beyond the matrix: only the matrix's last range (wave-uniform; the fold of EVERY
-    // tile of that range then carries the row mask, which costs that one range a few instructions per score)
-    const bool ragged = n0 + SCAN2_RANGE > n_valid;
     if (wr == 1) barrier();               // stagger: group 1 runs one barrier behind group 0
-    int kk = 0, t = 0;
     const std::true_type T{}; const std::false_type F{};
-    for (int kt = 0; kt < total; kt += 2) {              // nk is even: a row tile starts on an even kt and ends on an odd one
-        const bool first = kk == 0, last = kk + 2 == nk;
-        if (__builtin_expect(ragged, 0)) {
-            if (first) tile(T, F, T, kt, 0, t > 0, t, kk); else tile(F, F, T, kt, 0, false, t, kk);
-            ++kk;
-            if (last) tile(F, T, T, kt + 1, 1, false, t, kk); else tile(F, F, T, kt + 1, 1, false, t, kk);
-        } else {
-            if (first) tile(T, F, F, kt, 0, t > 0, t, kk); else tile(F, F, F, kt, 0, false, t, kk);
-            ++kk;
-            if (last) tile(F, T, F, kt + 1, 1, false, t, kk); else tile(F, F, F, kt + 1, 1, false, t, kk);
+    const std::integral_constant<int, 0> MID{}; const std::integral_constant<int, 1> FIRST{}; const std::integral_constant<int, 2> LAST{};
+    // Row tile 0's first K-tile also "folds the previous row tile's" quadrants (1,1) (1,0): those accumulators start at MASKED
+    // instead of 0, so what enters the running keys there loses to every real score (each stream sees 128 of them) and the
+    // fold's clear leaves the accumulators at 0 before their first MFMA — no t == 0 copy of the K-tile body.
+    auto run = [&](auto ragged_tag) __attribute__((always_inline)) {
+        int kt = 0;
+        for (int t = 0; t < 8; ++t) {
+            tile(FIRST, ragged_tag, kt, 0, t, 0); ++kt;
+            for (int kk = 1; kk + 1 < nk; kk += 2) {     // nk even: the K-tiles between first and last come in pairs
+                tile(MID, ragged_tag, kt, 1, t, kk); ++kt;
+                tile(MID, ragged_tag, kt, 0, t, kk + 1); ++kt;
+            }
+            tile(LAST, ragged_tag, kt, 1, t, nk - 1); ++kt;
         }
-        if (++kk == nk) { kk = 0; ++t; }
-    }
-    // the last row tile's second half: nothing left to hide it behind
-    if (DIAG != 1) {
-        auto tail = [&](auto ragged_tag) __attribute__((always_inline)) {
+        // the last row tile's second half: nothing left to hide it behind
+        if constexpr (DIAG != 1) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {                // quadrants (1,1) then (1,0)
                 const int hn = q == 0 ? 1 : 0;
@@ -281,9 +298,16 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
                     mm[(4 + i) * 64] = p;
                 }
             }
-        };
-        if (ragged) tail(T); else tail(F);
-    }
+        } else {                                         // diagnostic: one fold at the very end keeps the MFMAs alive
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                float2 p = mm[mi * 64];
+                fold_block(ragged_tag, mi, 0, 7, p); fold_block(ragged_tag, mi, 1, 7, p);
+                mm[mi * 64] = p;
+            }
+        }
+    };
+    if (__builtin_expect(ragged, 0)) run(T); else run(F);
     if (wr == 0) barrier();               // every wave executes the same number of barriers
 #undef VQ_VMCNT
 

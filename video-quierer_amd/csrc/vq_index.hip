@@ -7,6 +7,7 @@
 #include "knn_scan_f16.h"
 #include "knn_fallback.h"
 #include "knn_scan_deep.h"
+#include "knn_scan_fold.h"
 
 #include <algorithm>
 #include <atomic>
@@ -52,7 +53,8 @@ struct vq_index {
     uint32_t* d_norm_range = nullptr;
     bool norm_dirty = false, near_unit = true;
     float row_norm_max = 1.0f;
-    int scan_version = 4;          // $VQ_AMD_SCAN: 4 = 256x256 deep-prefetch mainloop (needs dim % 128 == 0), 2 = 256x256 four-phase, 1 = 128x128
+    int scan_version = 5;          // $VQ_AMD_SCAN: 5 = deep-prefetch mainloop with the fold spread behind the MFMA clusters (needs dim % 128 == 0), 4 = the same with
+                                   // the fold at the row-tile boundary, 2 = 256x256 four-phase, 1 = 128x128; diagnostic builds: 51 / 52 = scan5 without fold / fold not interleaved
     bool no_small_scan = false;    // $VQ_AMD_SCAN_SMALL=0: batches of <= SCAN3_MAX_Q queries also take the MFMA-tile scan (A/B switch)
     bool profiling = false;
     struct Ev { int cls; hipEvent_t a, b; };
@@ -187,6 +189,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     const int ver = small ? 3 : x->scan_version;                       // 3: streaming, 2: 256x256 phased mainloop, 1: 128x128
     const int nqg3 = nq > SCAN3_QB && x->dim <= 512 ? 2 : 1;           // query groups the streaming scan holds per pass (768-d: 96 + 96 VGPRs for one)
     const int QT = ver == 3 ? SCAN3_QB * nqg3 : ver >= 2 ? SCAN2_QT : SCAN_QT;
+    const bool deep = ver == 4 || ver >= 5;                            // the 2048-row-range kernels that share scan2's key layout
     const int RANGE = ver == 3 ? SCAN_STREAM_ROWS : ver >= 2 ? SCAN2_RANGE : SCAN_RANGE;
     const int64_t n_pad = round_up(n, RANGE);
     const int64_t streams = n_pad / SCAN_STREAM_ROWS;
@@ -219,13 +222,19 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             attr3_set = true;
         }
     }
-    if (ver == 2 || ver == 4) {
+    if (ver == 2 || deep) {
         static std::atomic<bool> attr_set{false};
         if (!attr_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)scan2_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G2_LDS_BYTES));
             VQ_HIP(hipFuncSetAttribute((const void*)scan4_f16_top2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SCAN4_LDS_BYTES));
+            VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SCAN4_LDS_BYTES));
+#ifdef VQ_DIAG
+            VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN4_LDS_BYTES));
+            VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN4_LDS_BYTES));
+#endif
             attr_set = true;
         }
     }
@@ -247,9 +256,17 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
                            : x->dim == 512 ? (nqg3 == 2 ? scan3_f16_top2_kernel<16, 2> : scan3_f16_top2_kernel<16, 1>)
                                            : (nqg3 == 2 ? scan3_f16_top2_kernel<8, 2> : scan3_f16_top2_kernel<8, 1>);
                 hipLaunchKernelGGL(scan3, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams, q_pad, x->d_keys);
-            } else if (ver == 2 || ver == 4) {
+            } else if (ver == 2 || deep) {
                 const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
-                if (ver == 4)
+                if (ver >= 5) {
+                    auto k5 = scan5_f16_top2_kernel<0>;
+#ifdef VQ_DIAG
+                    if (ver == 51) k5 = scan5_f16_top2_kernel<1>;
+                    if (ver == 52) k5 = scan5_f16_top2_kernel<2>;
+#endif
+                    hipLaunchKernelGGL(k5, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
+                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
+                } else if (ver == 4)
                     hipLaunchKernelGGL(scan4_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
                                        x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
                 else
@@ -269,7 +286,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                               d_dist_out + q0 * k, x->d_flags + q0, ver == 4 ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
+                               d_dist_out + q0 * k, x->d_flags + q0, deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
         }
     }
     VQ_HIP(hipGetLastError());
@@ -338,7 +355,7 @@ int vq_index_create(int dim, vq_index** out) {
     VQ_CHECK(out && dim > 0 && dim % 4 == 0 && dim <= 4096, "vq_index_create: dim %d must be a positive multiple of 4", dim);
     vq_index* x = new vq_index();
     x->dim = dim;
-    if (const char* sv = getenv("VQ_AMD_SCAN")) { const int v = atoi(sv); x->scan_version = (v == 1 || v == 2) ? v : 4; }
+    if (const char* sv = getenv("VQ_AMD_SCAN")) { const int v = atoi(sv); x->scan_version = (v == 1 || v == 2 || v == 4 || v == 51 || v == 52) ? v : 5; }
     if (dim % 128 != 0) x->scan_version = 1;
     if (const char* ss = getenv("VQ_AMD_SCAN_SMALL")) x->no_small_scan = atoi(ss) == 0;
     hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
