@@ -458,47 +458,54 @@ __device__ __forceinline__ float exact_dot_chain(const float* __restrict__ row, 
 
 // keys carry the sign of the score, so compare them as floats; ties and the
 // packed low bits do not matter for the proof (only upper bounds are used).
+// Template: QPW queries per workgroup, KEEP keys kept per (query, share), C candidates re-scored exactly.  <8, 6, 32> serves
+// k <= RV_K_SMALL (what round 2 shipped); <4, 10, 80> serves k up to RV_K_MAX = 64 — the caller over-fetches k * 2
+// (video_search_system.py:297), and a proof needs the (C+1)-th key at least a bound's width below the k-th exact score, i.e.
+// C well above k: with C = 32, k in (20, 32] sent nearly every query to the exact fallback.  layout 3 = the streaming scan's
+// query-major keys (small batches with k > RV_K_SMALL come here instead of rescore_verify_small_kernel).
+template <int QPW, int KEEP, int C>
 __global__ __launch_bounds__(256)
-void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
+void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
                            const float* __restrict__ rows, int64_t n_valid, int dim,
                            const float* __restrict__ queries, int nq, int k,
                            int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
                            int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2, 3: scan3_f16_top2 streams*/,
                            float eps_rows /* scan_eps_unit(dim) x the largest |row| in the index */) {
-    __shared__ float kept_v[RV_QPW][RV_SHARES * RV_KEEP];      // kept key values (with packed index bits)
-    __shared__ int kept_s[RV_QPW][RV_SHARES * RV_KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
-    __shared__ float share_floor[RV_QPW][RV_SHARES];           // upper bound of what a share dropped
-    __shared__ int cand_row[RV_QPW][RV_POOL];                  // rows scored exactly
-    __shared__ float cand_dist[RV_QPW][RV_POOL];
-    __shared__ float cand_key[RV_QPW][RV_C];                   // approx key value of candidate c
-    __shared__ int cand_src[RV_QPW][RV_C];
-    __shared__ int pool_n[RV_QPW];
-    __shared__ float bound_rest[RV_QPW];                       // (C+1)-th kept key
-    __shared__ int resc_stream[RV_QPW][RV_RESCAN_MAX];
-    __shared__ int resc_n[RV_QPW];
-    __shared__ int state[RV_QPW];
-    __shared__ float qn2[RV_QPW][RV_SHARES];                   // partial |q|^2 (the bound scales with |q|)
-    __shared__ float dk_s[RV_QPW];                             // k-th smallest exact distance among the candidates
+    constexpr int SHARES = 256 / QPW, TPQ = 256 / QPW, POOL = C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;
+    __shared__ float kept_v[QPW][SHARES * KEEP];      // kept key values (with packed index bits)
+    __shared__ int kept_s[QPW][SHARES * KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
+    __shared__ float share_floor[QPW][SHARES];           // upper bound of what a share dropped
+    __shared__ int cand_row[QPW][POOL];                  // rows scored exactly
+    __shared__ float cand_dist[QPW][POOL];
+    __shared__ float cand_key[QPW][C];                   // approx key value of candidate c
+    __shared__ int cand_src[QPW][C];
+    __shared__ int pool_n[QPW];
+    __shared__ float bound_rest[QPW];                       // (C+1)-th kept key
+    __shared__ int resc_stream[QPW][RV_RESCAN_MAX];
+    __shared__ int resc_n[QPW];
+    __shared__ int state[QPW];
+    __shared__ float qn2[QPW][SHARES];                   // partial |q|^2 (the bound scales with |q|)
+    __shared__ float dk_s[QPW];                             // k-th smallest exact distance among the candidates
 
     const int tid = threadIdx.x;
-    const int ql = tid % RV_QPW, share = tid / RV_QPW;
-    const int q0 = blockIdx.x * RV_QPW;
+    const int ql = tid % QPW, share = tid / QPW;
+    const int q0 = blockIdx.x * QPW;
     const int q = q0 + ql;
     const float NEG = -__builtin_inff();
 
-    // ---- 1. each thread keeps the best RV_KEEP keys of its share (streams s = share mod 16) ----
-    float kv[RV_KEEP]; int ksrc[RV_KEEP];
+    // ---- 1. each thread keeps the best KEEP keys of its share (streams s = share mod 16) ----
+    float kv[KEEP]; int ksrc[KEEP];
 #pragma unroll
-    for (int i = 0; i < RV_KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
+    for (int i = 0; i < KEEP; ++i) { kv[i] = NEG; ksrc[i] = -1; }
     float dropped = NEG;
     // Insertion by compare-and-swap down the sorted list, as SELECTS: written with `if (v > kv[i]) swap` the compiler built an
     // exec-mask branch per step (~70 instructions per offer, and a wave runs the insertion whenever any of its lanes inserts);
     // raw v_max for the floor (fmaxf costs a canonicalising pre-max per operand in IEEE mode; the keys are never NaN).
     auto raw_max = [](float a, float b) __attribute__((always_inline)) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto offer = [&](float v, int src) __attribute__((always_inline)) {
-        if (v > kv[RV_KEEP - 1]) {
+        if (v > kv[KEEP - 1]) {
 #pragma unroll
-            for (int i = 0; i < RV_KEEP; ++i) {
+            for (int i = 0; i < KEEP; ++i) {
                 const bool gt = v > kv[i];
                 const float hi = gt ? v : kv[i], lo = gt ? kv[i] : v;
                 const int shi = gt ? src : ksrc[i], slo = gt ? ksrc[i] : src;
@@ -512,23 +519,26 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     // batches of eight 8-byte loads, the next batch in flight while the current one is offered (one batch at a time waited a
     // full memory round trip per batch: 194k cycles for 32 batches)
     constexpr int PF = 8;
+    auto key_at = [&](int64_t st) __attribute__((always_inline)) {       // element index of stream st's key pair of query q
+        return layout == 3 ? ((size_t)q * streams + st) * 2 : batch_key_index(st, q, streams);
+    };
     int64_t s = share;
     uint2 two[PF], nxt[PF];
-    const bool any_full = s + (PF - 1) * RV_SHARES < streams;
+    const bool any_full = s + (PF - 1) * SHARES < streams;
     if (any_full) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + batch_key_index(s + u * RV_SHARES, q, streams));   // a wave: 8 adjacent 128-byte blocks
+        for (int u = 0; u < PF; ++u) two[u] = *(const uint2*)(keys + key_at(s + u * SHARES));   // a wave: 8 adjacent 128-byte blocks
     }
-    for (; s + (PF - 1) * RV_SHARES < streams; s += PF * RV_SHARES) {
-        const int64_t sn = s + PF * RV_SHARES;
-        const bool more = sn + (PF - 1) * RV_SHARES < streams;
+    for (; s + (PF - 1) * SHARES < streams; s += PF * SHARES) {
+        const int64_t sn = s + PF * SHARES;
+        const bool more = sn + (PF - 1) * SHARES < streams;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) nxt[u] = *(const uint2*)(keys + batch_key_index(sn + u * RV_SHARES, q, streams));
+            for (int u = 0; u < PF; ++u) nxt[u] = *(const uint2*)(keys + key_at(sn + u * SHARES));
         }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int src = (int)((s + u * RV_SHARES) * 2);
+            const int src = (int)((s + u * SHARES) * 2);
             offer(__builtin_bit_cast(float, two[u].x), src);
             offer(__builtin_bit_cast(float, two[u].y), src + 1);
         }
@@ -537,30 +547,30 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             for (int u = 0; u < PF; ++u) two[u] = nxt[u];
         }
     }
-    for (; s < streams; s += RV_SHARES) {
-        const uint2 two = *(const uint2*)(keys + batch_key_index(s, q, streams));
+    for (; s < streams; s += SHARES) {
+        const uint2 two = *(const uint2*)(keys + key_at(s));
         offer(__builtin_bit_cast(float, two.x), (int)(s * 2));
         offer(__builtin_bit_cast(float, two.y), (int)(s * 2 + 1));
     }
 #pragma unroll
-    for (int i = 0; i < RV_KEEP; ++i) { kept_v[ql][share * RV_KEEP + i] = kv[i]; kept_s[ql][share * RV_KEEP + i] = ksrc[i]; }
+    for (int i = 0; i < KEEP; ++i) { kept_v[ql][share * KEEP + i] = kv[i]; kept_s[ql][share * KEEP + i] = ksrc[i]; }
     share_floor[ql][share] = dropped;
-    if (tid < RV_QPW) { pool_n[tid] = 0; resc_n[tid] = 0; state[tid] = 0; }
+    if (tid < QPW) { pool_n[tid] = 0; resc_n[tid] = 0; state[tid] = 0; }
     __syncthreads();
 
     // ---- 2. per query (one 16-lane group each): the best C of the 128 kept keys, by rank counting ----
     //      rank(i) = #{j : v_j > v_i or (v_j == v_i and j < i)}; unique ranks 0..127
     {
-        const int qq = tid / RV_TPQ, l16 = tid % RV_TPQ;       // RV_TPQ threads per query here
-        for (int i = l16; i < RV_SHARES * RV_KEEP; i += RV_TPQ) {
+        const int qq = tid / TPQ, l16 = tid % TPQ;       // TPQ threads per query here
+        for (int i = l16; i < SHARES * KEEP; i += TPQ) {
             const float vi = kept_v[qq][i];
             int rank = 0;
-            for (int j = 0; j < RV_SHARES * RV_KEEP; ++j) {
+            for (int j = 0; j < SHARES * KEEP; ++j) {
                 const float vj = kept_v[qq][j];
                 rank += (vj > vi) || (vj == vi && j < i);
             }
-            if (rank < RV_C) { cand_key[qq][rank] = vi; cand_src[qq][rank] = kept_s[qq][i]; }
-            if (rank == RV_C) bound_rest[qq] = vi;
+            if (rank < C) { cand_key[qq][rank] = vi; cand_src[qq][rank] = kept_s[qq][i]; }
+            if (rank == C) bound_rest[qq] = vi;
         }
     }
     __syncthreads();
@@ -570,10 +580,10 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     const float* qv = queries + (size_t)(q_live ? q : 0) * dim;
     {
         float s2 = 0.f;
-        for (int i = share; i < dim; i += RV_SHARES) s2 += qv[i] * qv[i];
+        for (int i = share; i < dim; i += SHARES) s2 += qv[i] * qv[i];
         qn2[ql][share] = s2;
     }
-    for (int c = share; c < RV_C; c += RV_SHARES) {
+    for (int c = share; c < C; c += SHARES) {
         const int src = cand_src[ql][c];
         int row = -1; float d = __builtin_inff();
         if (src >= 0 && q_live && cand_key[ql][c] > NEG) {
@@ -590,28 +600,28 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
     // 4a. the k-th smallest exact distance among the C candidates, selection by counting: thread (query, candidate) — one
     //     thread per query doing all C^2 comparisons held the workgroup for 215k of its 815k cycles
     {
-        const int kk = k < RV_C ? k : RV_C;
-        if (tid < RV_QPW) dk_s[tid] = __builtin_inff();
+        const int kk = k < C ? k : C;
+        if (tid < QPW) dk_s[tid] = __builtin_inff();
         __syncthreads();
-        for (int c = share; c < RV_C; c += RV_SHARES) {
+        for (int c = share; c < C; c += SHARES) {
             if (cand_row[ql][c] < 0) continue;
             const uint64_t ki = dist_key(cand_dist[ql][c], (uint32_t)cand_row[ql][c]);
             int rank = 0;
-            for (int j = 0; j < RV_C; ++j)
+            for (int j = 0; j < C; ++j)
                 rank += cand_row[ql][j] >= 0 && dist_key(cand_dist[ql][j], (uint32_t)cand_row[ql][j]) < ki;
             if (rank == kk - 1) dk_s[ql] = cand_dist[ql][c];            // keys are distinct (the row is in the key): one writer
         }
         __syncthreads();
     }
-    if (tid < RV_QPW && q0 + tid < nq) {
+    if (tid < QPW && q0 + tid < nq) {
         const int qq = tid;
-        const int kk = k < RV_C ? k : RV_C;
+        const int kk = k < C ? k : C;
         int have = 0;
-        for (int i = 0; i < RV_C; ++i) have += cand_row[qq][i] >= 0;
+        for (int i = 0; i < C; ++i) have += cand_row[qq][i] >= 0;
         const float dk = have >= kk ? dk_s[qq] : __builtin_inff();
         const float sk = 1.0f - dk;                            // k-th best exact score (−inf if fewer than k rows exist)
         float q2 = 0.f;
-        for (int sh = 0; sh < RV_SHARES; ++sh) q2 += qn2[qq][sh];
+        for (int sh = 0; sh < SHARES; ++sh) q2 += qn2[qq][sh];
         const float SCAN_EPS = eps_rows * sqrtf(q2);           // NaN for a non-finite query: every test below fails -> exact fallback
         int st = 0;
         const bool all_rows_scored = n_valid <= 0;
@@ -620,11 +630,11 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             st = 2;                                            // fewer than k distinct rows among the candidates, or a query the fp16 bound does not cover
         } else {
             if (!(bound_rest[qq] + SCAN_EPS < sk)) st = 2;     // kept keys outside the best C could still matter
-            for (int sh = 0; sh < RV_SHARES; ++sh)
+            for (int sh = 0; sh < SHARES; ++sh)
                 if (!(share_floor[qq][sh] + SCAN_EPS < sk)) st = 2;   // a share dropped a key that could matter
             if (st == 0) {
                 // a stream whose 2nd key is among the candidates hides rows bounded only by that key
-                for (int c = 0; c < RV_C; ++c) {
+                for (int c = 0; c < C; ++c) {
                     if ((cand_src[qq][c] & 1) && cand_key[qq][c] + SCAN_EPS >= sk) {
                         if (resc_n[qq] < RV_RESCAN_MAX) resc_stream[qq][resc_n[qq]++] = cand_src[qq][c] >> 1;
                         else st = 2;
@@ -634,12 +644,12 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
             }
         }
         state[qq] = st;
-        pool_n[qq] = RV_C;
+        pool_n[qq] = C;
     }
     __syncthreads();
 
     // ---- 5. stream rescans: all 128 rows of each suspicious stream, exactly ----
-    for (int qq = 0; qq < RV_QPW; ++qq) {
+    for (int qq = 0; qq < QPW; ++qq) {
         if (state[qq] != 1) continue;                           // block-uniform (LDS value)
         const int nres = resc_n[qq];
         const float* qv2 = queries + (size_t)(q0 + qq) * dim;
@@ -649,29 +659,29 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                             : layout == 2 ? scan2_row_of(resc_stream[qq][which], local) : scan_row_of(resc_stream[qq][which], local);
             int row = -1; float d = __builtin_inff();
             if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain_pf(rows + (size_t)r * dim, qv2, dim); }
-            cand_row[qq][RV_C + i] = row; cand_dist[qq][RV_C + i] = d;
+            cand_row[qq][C + i] = row; cand_dist[qq][C + i] = d;
         }
-        if (tid == 0) pool_n[qq] = RV_C + nres * SCAN_STREAM_ROWS;
+        if (tid == 0) pool_n[qq] = C + nres * SCAN_STREAM_ROWS;
     }
     __syncthreads();
 
     // ---- 6. final exact top-k of the pool by (distance, row); duplicates collapse (same key) ----
     {
-        const int qq = tid / RV_TPQ, l16 = tid % RV_TPQ;
+        const int qq = tid / TPQ, l16 = tid % TPQ;
         if (q0 + qq < nq) {
             const int pn = pool_n[qq];
             if (l16 == 0) flags[q0 + qq] = state[qq];
             uint64_t prev = 0; bool have_prev = false;
             for (int j = 0; j < k; ++j) {
                 uint64_t best = ~0ull;
-                for (int i = l16; i < pn; i += RV_TPQ) {
+                for (int i = l16; i < pn; i += TPQ) {
                     if (cand_row[qq][i] < 0) continue;
                     const uint64_t key = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
                     if ((!have_prev || key > prev) && key < best) best = key;
                 }
 #pragma unroll
-                for (int o = RV_TPQ / 2; o > 0; o >>= 1) {
-                    const uint64_t other = __shfl_xor(best, o, RV_TPQ);
+                for (int o = TPQ / 2; o > 0; o >>= 1) {
+                    const uint64_t other = __shfl_xor(best, o, TPQ);
                     best = other < best ? other : best;
                 }
                 if (l16 == 0) {
@@ -681,7 +691,7 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
                 }
                 prev = best; have_prev = true;
                 if (best == ~0ull) {
-                    for (int jj = j + 1 + l16; jj < k; jj += RV_TPQ) {
+                    for (int jj = j + 1 + l16; jj < k; jj += TPQ) {
                         out_ids[(size_t)(q0 + qq) * k + jj] = -1; out_dist[(size_t)(q0 + qq) * k + jj] = __builtin_inff();
                     }
                     break;
@@ -690,6 +700,12 @@ void rescore_verify_kernel(const uint32_t* __restrict__ keys, int64_t streams, i
         }
     }
 }
+
+// the instantiation round 2 shipped, under its old name
+constexpr int RV_K_SMALL = 20, RV_K_MAX = 64;
+constexpr int RVL_QPW = 4, RVL_KEEP = 10, RVL_C = 80;
+static const auto rescore_verify_kernel = rescore_verify_kernel_t<RV_QPW, RV_KEEP, RV_C>;
+static const auto rescore_verify_large_kernel = rescore_verify_kernel_t<RVL_QPW, RVL_KEEP, RVL_C>;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small batches (nq <= SCAN3_MAX_Q, keys in layout 3): ONE workgroup per query instead of 16 queries per workgroup.

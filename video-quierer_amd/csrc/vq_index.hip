@@ -279,7 +279,12 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         }
         {
             Prof p(x, I_RESCORE);
-            if (ver == 3)
+            const bool large = k > RV_K_SMALL;                  // k in (20, 64]: the wide candidate pool, whatever scan produced the keys
+            if (large)
+                hipLaunchKernelGGL(rescore_verify_large_kernel, dim3(cdiv(cur, RVL_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
+                                   q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
+                                   d_dist_out + q0 * k, x->d_flags + q0, ver == 3 ? 3 : deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
+            else if (ver == 3)
                 hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), (size_t)(RV_C * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
                                    x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
                                    scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? x->d_counters : nullptr);
@@ -294,7 +299,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // list and the fallback kernels size themselves from its length (all of them leave at once when it is empty), so
     // nothing here waits for the stream.  Rounds beyond the first exist only when more queries could be flagged than
     // one round's scratch holds.
-    if (!(ver == 3 && nq == 1))             // a single query's re-score workgroup has written the list and the counters itself
+    if (!(ver == 3 && nq == 1 && k <= RV_K_SMALL))   // a single query's (small-k) re-score workgroup has written the list and the counters itself
         hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
     {
         Prof p(x, I_EXACT_DIST);
@@ -320,9 +325,9 @@ int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode
     // rows were added un-normalised ON THE DEVICE since the last look (vq_index_add_device: the one add that does not block):
     // is the matrix still near-unit?  This is the only place a search waits for its stream.
     if (mode != 1) VQ_TRY(refresh_norm_range(x));
-    const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_C && x->size >= 1 && x->near_unit;
+    const bool fp16_ok = x->dim % GEMM_BK == 0 && k <= RV_K_MAX && x->size >= 1 && x->near_unit;
     if (mode == 2) VQ_CHECK(fp16_ok, "vq_index_search: fp16 scan needs dim %% 64 == 0, k <= %d and near-unit rows "
-                                     "(0.5 <= |row|^2 <= 2; rows added with normalize=0 are measured)", RV_C);
+                                     "(0.5 <= |row|^2 <= 2; rows added with normalize=0 are measured)", RV_K_MAX);
     // auto: the MFMA scan pays once the matrix is large enough to amortise its fixed costs
     const bool use_fp16 = mode == 2 || (mode == 0 && fp16_ok && x->size >= 16384);
     return use_fp16 ? search_fp16(x, d_queries, nq, k, d_ids, d_dist) : search_exact(x, d_queries, nq, k, d_ids, d_dist);
