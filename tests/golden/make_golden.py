@@ -12,8 +12,9 @@ Produces
                              build's seeded weights: L2-normalised [64,512] fp32
                              embeddings, the un-normalised features, and a
                              checksum of the frames/weights they came from.
-  encoder_l14_336_seed1234.npz   (`make_golden.py l14`) 2 frames through the ViT-L/14@336 geometry.
+  encoder_l14_336_seed1234.npz   (`make_golden.py l14`) 32 frames through the ViT-L/14@336 geometry.
   text_b32_seed1234.npz      (`make_golden.py text`) 16 synthetic prompts (token ids) through the text tower.
+  text_l14_seed1234.npz      (`make_golden.py text_l14`) the same prompts through the ViT-L/14 text tower (768 wide).
   resample_pil.npz           (`make_golden.py resample`) Pillow's resize / transformers' CLIP image processor on
                              seeded frames: two full outputs + SHA-256 of all eight (inputs are regenerated
                              from the seed by resample_input()).
@@ -88,7 +89,7 @@ def capture_encoder():
 
 
 def capture_encoder_l14():
-    """ViT-L/14@336 (BASELINE configs[4]): 2 synthetic 336x336 frames through transformers' CLIP with the
+    """ViT-L/14@336 (BASELINE configs[4]): 32 synthetic 336x336 frames through transformers' CLIP with the
     build's seeded L/14 weights — pins the 577-token / patch-14 / hidden-1024 path of the restatement."""
     import torch
     from transformers import CLIPConfig, CLIPModel
@@ -105,14 +106,17 @@ def capture_encoder_l14():
         assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
         sd[k] = torch.from_numpy(v)
     model.load_state_dict(sd)
-    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
-    x = torch.from_numpy(np.ascontiguousarray(frames[..., ::-1])).permute(0, 3, 1, 2).float() / 255.0
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (32, 336, 336, 3), dtype=np.uint8)     # (the first 2 = round 1's fixture)
     mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
     std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    embs = []
     with torch.no_grad():
-        out = model.get_image_features((x - mean) / std)
-        feats = out.pooler_output if hasattr(out, "pooler_output") else out
-        emb = torch.nn.functional.normalize(feats, p=2, dim=1)
+        for i in range(0, len(frames), 8):
+            x = torch.from_numpy(np.ascontiguousarray(frames[i:i + 8, ..., ::-1])).permute(0, 3, 1, 2).float() / 255.0
+            out = model.get_image_features((x - mean) / std)
+            feats = out.pooler_output if hasattr(out, "pooler_output") else out
+            embs.append(torch.nn.functional.normalize(feats, p=2, dim=1))
+    emb = torch.cat(embs)
     np.savez_compressed(os.path.join(HERE, "encoder_l14_336_seed1234.npz"), embeddings=emb.numpy().astype(np.float32),
                         frame_seed=FRAME_SEED, weight_seed=WEIGHT_SEED,
                         frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
@@ -152,6 +156,32 @@ def capture_text():
         feats = out.pooler_output if hasattr(out, "pooler_output") else out
         emb = torch.nn.functional.normalize(feats, p=2, dim=1)
     np.savez_compressed(os.path.join(HERE, "text_b32_seed1234.npz"), input_ids=ids.astype(np.int32),
+                        embeddings=emb.numpy().astype(np.float32), weight_seed=WEIGHT_SEED)
+
+
+def capture_text_l14():
+    """The ViT-L/14 text tower (12 x 768, 12 heads, projection 768: configs[4]'s "mixed text+image queries",
+    feature_extractor.py:218-234) on the same 16 synthetic prompts."""
+    import torch
+    from transformers import CLIPConfig, CLIPModel
+    from video_quierer_amd.weights import TEXT_L_14, seeded_text_weights
+
+    W = seeded_text_weights(TEXT_L_14, WEIGHT_SEED)
+    cfg = CLIPConfig(text_config=dict(hidden_size=TEXT_L_14.hidden, intermediate_size=TEXT_L_14.mlp, num_attention_heads=TEXT_L_14.heads,
+                                      num_hidden_layers=TEXT_L_14.layers, projection_dim=TEXT_L_14.proj_dim),
+                     vision_config=dict(num_hidden_layers=1), projection_dim=TEXT_L_14.proj_dim)
+    model = CLIPModel(cfg).eval()
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    ids = synth_token_ids()
+    with torch.no_grad():
+        out = model.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.ones_like(torch.from_numpy(ids)))
+        feats = out.pooler_output if hasattr(out, "pooler_output") else out
+        emb = torch.nn.functional.normalize(feats, p=2, dim=1)
+    np.savez_compressed(os.path.join(HERE, "text_l14_seed1234.npz"), input_ids=ids.astype(np.int32),
                         embeddings=emb.numpy().astype(np.float32), weight_seed=WEIGHT_SEED)
 
 
@@ -297,6 +327,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "text" in sys.argv[1:]:
         capture_text()
+    if "text_l14" in sys.argv[1:]:
+        capture_text_l14()
         sys.exit(0)
     emb = capture_encoder()
     capture_knn(emb)

@@ -976,13 +976,13 @@ def test_encoder_vit_l14_336_matches_golden(gpu_lib):
     from video_quierer_amd.encoder import VitEncoder
     from video_quierer_amd.weights import VIT_L_14_336, seeded_weights
     g = np.load(os.path.join(GOLDEN, "encoder_l14_336_seed1234.npz"))
-    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (32, 336, 336, 3), dtype=np.uint8)      # one bench-sized batch (--model l14 --batch 32)
     W = seeded_weights(VIT_L_14_336, 1234)
     for dt, tol in (("fp16", 2e-3), ("bf16", 1.5e-2)):
-        enc = VitEncoder(VIT_L_14_336, W, max_batch=2, compute_dtype=dt)
+        enc = VitEncoder(VIT_L_14_336, W, max_batch=32, compute_dtype=dt)
         emb = enc.encode(frames)
         enc.close()
-        assert emb.shape == (2, 768)
+        assert emb.shape == (32, 768)
         err = np.linalg.norm(emb - g["embeddings"], axis=1).max()
         cos = np.sum(emb * g["embeddings"], axis=1).min()
         print(f"ViT-L/14@336 {dt}: max L2 err {err:.2e}, min cos {cos:.7f}")
@@ -1008,6 +1008,22 @@ def test_text_tower_matches_golden(gpu_lib):
         assert np.abs(short[0] - emb[1]).max() <= 1e-6                        # padding is invisible to the EOS position
     ref = clip_vit_oracle.encode_token_ids(g["input_ids"], W)
     assert np.abs(ref - g["embeddings"]).max() <= 1e-5
+
+
+def test_text_tower_l14_matches_golden(gpu_lib):
+    """configs[4]'s "mixed text+image queries": the ViT-L/14 text tower (768 wide, 12 heads, projection 768) on the 16 synthetic
+    prompts against transformers' get_text_features on the same seeded weights (tests/golden/text_l14_seed1234.npz)."""
+    from video_quierer_amd.text_encoder import TextEncoder
+    from video_quierer_amd.weights import TEXT_L_14, seeded_text_weights
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "text_l14_seed1234.npz"))
+    W = seeded_text_weights(TEXT_L_14, 1234)
+    enc = TextEncoder(TEXT_L_14, W, max_batch=16, compute_dtype="fp16")
+    emb = enc.encode_ids(g["input_ids"])
+    enc.close()
+    err = np.linalg.norm(emb - g["embeddings"], axis=1)
+    print(f"ViT-L/14 text tower fp16: max L2 err {err.max():.2e}, min cos {np.sum(emb * g['embeddings'], axis=1).min():.7f}")
+    assert emb.shape == (16, 768) and err.max() <= 1.5e-3 and np.sum(emb * g["embeddings"], axis=1).min() >= 1 - COS_TOL
 
 
 def test_feature_extractor_text_ids(gpu_lib):

@@ -109,12 +109,13 @@ def test_encoder_oracle_matches_transformers_vit_l14_336():
     from conftest import GOLDEN, FRAME_SEED
     from video_quierer_amd.weights import VIT_L_14_336, seeded_weights
     g = np.load(os.path.join(GOLDEN, "encoder_l14_336_seed1234.npz"))
-    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (2, 336, 336, 3), dtype=np.uint8)
+    frames = np.random.default_rng(FRAME_SEED).integers(0, 255, (32, 336, 336, 3), dtype=np.uint8)
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
     cfg = VIT_L_14_336
-    emb = clip_vit_oracle.encode_frames(frames, seeded_weights(cfg, 1234), patch=cfg.patch_size, heads=cfg.heads,
+    # the fixture holds 32 frames (one bench-sized batch for the GPU test); the CPU suite re-runs the restatement on the first 2
+    emb = clip_vit_oracle.encode_frames(frames[:2], seeded_weights(cfg, 1234), patch=cfg.patch_size, heads=cfg.heads,
                                         layers=cfg.layers, batch_size=2)
-    assert emb.shape == (2, 768) and np.abs(emb - g["embeddings"]).max() <= 1e-5
+    assert g["embeddings"].shape == (32, 768) and emb.shape == (2, 768) and np.abs(emb - g["embeddings"][:2]).max() <= 1e-5
 
 
 def test_text_oracle_matches_transformers():
@@ -128,6 +129,17 @@ def test_text_oracle_matches_transformers():
     pad = np.full((g["input_ids"].shape[0], 77), 49407, dtype=np.int64)
     pad[:, :g["input_ids"].shape[1]] = g["input_ids"]
     assert np.array_equal(clip_vit_oracle.encode_token_ids(pad, W), emb)     # eos padding never reaches the pooled row
+
+
+def test_text_oracle_matches_transformers_l14_width():
+    """The ViT-L/14 text tower (768 wide, 12 heads, projection 768): the restatement against transformers' output."""
+    import os
+    from conftest import GOLDEN
+    from video_quierer_amd.weights import TEXT_L_14, seeded_text_weights
+    g = np.load(os.path.join(GOLDEN, "text_l14_seed1234.npz"))
+    W = seeded_text_weights(TEXT_L_14, 1234)
+    emb = clip_vit_oracle.encode_token_ids(g["input_ids"], W, heads=TEXT_L_14.heads, layers=TEXT_L_14.layers)
+    assert emb.shape == (16, 768) and np.abs(emb - g["embeddings"]).max() <= 1e-5
 
 
 # ------------------------------------------------------------------ resize in front of the encoder (§8f #3)
