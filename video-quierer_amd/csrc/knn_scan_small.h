@@ -27,15 +27,22 @@
 namespace vq {
 
 constexpr int SCAN3_QB = 16;            // queries per pass
+constexpr int SCAN3_FUSED_MAX_Q = 4;    // up to this many queries the scan converts them itself (template FUSED)
 constexpr int SCAN3_MAX_Q = 96;         // three 32-query passes (0.22 ms each over 1M x 512) still beat one 256-query MFMA tile (0.83 ms)
 
 __host__ __device__ inline int64_t scan3_row_of(int64_t stream, int local) { return stream * 128 + local; }
 
-template <int NKS, int NQG>             // dim / 32; groups of 16 queries per pass (1 or 2)
+// FUSED (one to four queries — the reference's own call is ONE): the queries arrive as fp32 [nq_real][dim] and are rounded to
+// fp16 here, by the lanes that hold a real query; the other lanes of the B operand are zero without a load, and only real
+// queries' keys are written.  That removes the conversion launch in front of a single-query search (~7 us of its ~210), the
+// 16 KiB of (mostly zero) fp16 query rows every one of the 31k waves used to fetch (0.5 GB of L2 reads beside the 1 GB matrix
+// stream) and 15 of 16 scattered 8-byte key stores per wave.  Same rounding (_Float16 cast = v_cvt_f16_f32, RNE) as
+// queries_to_f16_kernel: keys bit-identical to the two-launch path.
+template <int NKS, int NQG, bool FUSED = false>             // dim / 32; groups of 16 queries per pass (1 or 2)
 __global__ __launch_bounds__(256, 2)
-void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, const uint16_t* __restrict__ X16,
+void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]; FUSED: const float* [nq_real][dim]*/, const uint16_t* __restrict__ X16,
                            int64_t n_valid, int64_t streams, int64_t q_pad /* % (16 NQG) == 0 */,
-                           uint32_t* __restrict__ keys /*[q_pad][streams][2]*/) {
+                           uint32_t* __restrict__ keys /*[q_pad][streams][2]*/, int nq_real = 0 /* FUSED only */) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     constexpr int DIM = NKS * 32;
@@ -47,11 +54,25 @@ void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, co
     const int q0 = blockIdx.y * SCAN3_QB * NQG;
 
     frag qf[NQG][NKS];
+    if constexpr (FUSED) {
+        static_assert(NQG == 1, "the fused form serves up to four queries: one group");
+        const float* qsrc = (const float*)Q16 + (size_t)(r16 < nq_real ? r16 : 0) * DIM + g * 8;
 #pragma unroll
-    for (int qg = 0; qg < NQG; ++qg)
+        for (int ks = 0; ks < NKS; ++ks) {
+            frag f = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r16 < nq_real) {
+                const float4 a = *(const float4*)(qsrc + ks * 32), b = *(const float4*)(qsrc + ks * 32 + 4);
+                f = frag{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+            }
+            qf[0][ks] = f;
+        }
+    } else {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            qf[qg][ks] = *(const frag*)(Q16 + (size_t)(q0 + qg * SCAN3_QB + r16) * DIM + ks * 32 + g * 8);
+        for (int qg = 0; qg < NQG; ++qg)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                qf[qg][ks] = *(const frag*)(Q16 + (size_t)(q0 + qg * SCAN3_QB + r16) * DIM + ks * 32 + g * 8);
+    }
 
     const uint16_t* xrow = X16 + ((size_t)stream * 128 + r16) * DIM + g * 8;
     frag xf[NKS];
@@ -100,7 +121,7 @@ void scan3_f16_top2_kernel(const uint16_t* __restrict__ Q16 /*[q_pad][dim]*/, co
             m1[qg] = fmaxf(m1[qg], b1);
             m2[qg] = fmaxf(lo, fmaxf(m2[qg], b2));
         }
-        if (g == 0)
+        if (g == 0 && (!FUSED || r16 < nq_real))
             *(uint2*)(keys + ((size_t)(q0 + qg * SCAN3_QB + r16) * streams + stream) * 2) =
                 uint2{__builtin_bit_cast(uint32_t, m1[qg]), __builtin_bit_cast(uint32_t, m2[qg])};
     }

@@ -242,7 +242,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         const int cur = (int)std::min<int64_t>(q_chunk, nq - q0);
         const int64_t q_pad = round_up(cur, QT);
         const int q_tiles = (int)(q_pad / QT);
-        {
+        const bool fused_q = ver == 3 && nq <= SCAN3_FUSED_MAX_Q;      // the streaming scan rounds the (one to four) queries itself
+        if (!fused_q) {
             Prof p(x, I_TO_F16);
             const int64_t total4 = q_pad * x->dim / 4;
             hipLaunchKernelGGL(queries_to_f16_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0,
@@ -255,7 +256,13 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
                 auto scan3 = x->dim == 768 ? scan3_f16_top2_kernel<24, 1>
                            : x->dim == 512 ? (nqg3 == 2 ? scan3_f16_top2_kernel<16, 2> : scan3_f16_top2_kernel<16, 1>)
                                            : (nqg3 == 2 ? scan3_f16_top2_kernel<8, 2> : scan3_f16_top2_kernel<8, 1>);
-                hipLaunchKernelGGL(scan3, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams, q_pad, x->d_keys);
+                if (fused_q) {
+                    auto scan3f = x->dim == 768 ? scan3_f16_top2_kernel<24, 1, true> : x->dim == 512 ? scan3_f16_top2_kernel<16, 1, true>
+                                                                                                      : scan3_f16_top2_kernel<8, 1, true>;
+                    hipLaunchKernelGGL(scan3f, grid, dim3(256), 0, x->stream, (const uint16_t*)(d_queries + q0 * x->dim), x->rows16, n, streams,
+                                       q_pad, x->d_keys, cur);
+                } else
+                hipLaunchKernelGGL(scan3, grid, dim3(256), 0, x->stream, x->d_q16, x->rows16, n, streams, q_pad, x->d_keys, 0);
             } else if (ver == 2 || deep) {
                 const int range_groups = cdiv(ranges, 4), q_groups = cdiv(q_tiles, 8);
                 if (ver >= 5) {
