@@ -28,7 +28,7 @@ CLASSES = [        # (class name as bench.py's kernel_classes reports it, regex 
     ("gemm_out_proj_residual", r"gemm_tn.*EpiBiasResidual(Ln)?F32<0"),
     ("gemm_fc2_residual", r"gemm_tn.*EpiBiasResidual(Ln)?F32<1"),
     ("pool_project", r"pool_project"),
-    ("scan_f16_mfma_top2", r"scan[24]_f16_top2"),
+    ("scan_f16_mfma_top2", r"scan[245]_f16_top2"),
     ("scan_f16_stream_top2", r"scan3_f16_top2"),
     ("rescore_verify", r"rescore_verify"),
     ("resample_h", r"resample_h"),

@@ -52,7 +52,7 @@ template <int DIAG /* 0 = product; diagnostic builds: 1 = no fold at all (keys i
 __global__ __launch_bounds__(G2_THREADS, 2)
 void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
                            int dim, int64_t n_valid, int q_tiles, int n_ranges, int range_groups, int64_t q_pad,
-                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/) {
+                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/, int ldx /* row stride of X16, elements */) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,15 +76,15 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     const int arow_w = (wave >> 2) * 128 + (wave & 3) * 16, wrow_w = (wave >> 1) * 64 + (wave & 1) * 16;
     const int ar = arow_w + srow, wrw = wrow_w + srow;
     const int a_v0 = (ar * dim + (sslot ^ ((ar >> 1) & 7)) * 8) * 2, a_v1 = a_v0 ^ 64;
-    const int w_v0 = (wrw * dim + (sslot ^ ((wrw >> 1) & 7)) * 8) * 2, w_v1 = w_v0 ^ 64;
+    const int w_v0 = (wrw * ldx + (sslot ^ ((wrw >> 1) & 7)) * 8) * 2, w_v1 = w_v0 ^ 64;
     const int a_dst0 = arow_w * 128, w_dst0 = 2 * G2_HALF + wrow_w * 128;
-    const int row8 = 8 * dim * 2;
+    const int row8 = 8 * dim * 2, xrow8 = 8 * ldx * 2;
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(Q16 + (size_t)m0 * dim), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)(X16 + (size_t)n0 * dim), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)(X16 + (size_t)n0 * ldx), 0, 0x7fffffff, 0x00020000);
 
     const int nk = dim / G2_BK;                          // K-tiles per row tile (even)
     const int total = 8 * nk;
-    const int tile_bytes = 256 * dim * 2;
+    const int tile_bytes = 256 * ldx * 2;
 
     auto stage_a = [&](int buf, int hm, int kk) __attribute__((always_inline)) {
         char* base = smem + buf * G2_BUF + a_dst0 + hm * (64 * 128);
@@ -94,9 +94,9 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     };
     auto stage_w = [&](int buf, int hn, int t, int kk) __attribute__((always_inline)) {
         char* base = smem + buf * G2_BUF + w_dst0 + hn * (32 * 128);
-        const int soff = __builtin_amdgcn_readfirstlane(t * tile_bytes + kk * (G2_BK * 2) + hn * 4 * row8);
+        const int soff = __builtin_amdgcn_readfirstlane(t * tile_bytes + kk * (G2_BK * 2) + hn * 4 * xrow8);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + row8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + xrow8, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;

@@ -272,7 +272,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
                     if (ver == 52) k5 = scan5_f16_top2_kernel<2>;
 #endif
                     hipLaunchKernelGGL(k5, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
-                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
+                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys, x->dim);
                 } else if (ver == 4)
                     hipLaunchKernelGGL(scan4_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
                                        x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
