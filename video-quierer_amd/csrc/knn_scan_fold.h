@@ -52,7 +52,8 @@ template <int DIAG /* 0 = product; diagnostic builds: 1 = no fold at all (keys i
 __global__ __launch_bounds__(G2_THREADS, 2)
 void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
                            int dim, int64_t n_valid, int q_tiles, int n_ranges, int range_groups, int64_t q_pad,
-                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/, int ldx /* row stride of X16, elements */) {
+                           uint32_t* __restrict__ keys /*batch_key_index (knn_scan_f16.h)*/, int ldx /* row stride of X16, elements */,
+                           int rb_log2 = 2 /* 32 consecutive workgroups of an XCD = 2^rb_log2 row ranges x 32 / 2^rb_log2 query tiles */) {
     typedef mfma_op<true> op;
     typedef op::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,8 +66,9 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int blk = wg >> 5, inner = wg & 31;
     const int rg = blk % range_groups, qg = blk / range_groups;
-    const int range = rg * 4 + (inner >> 3);
-    const int qtile = qg * 8 + (inner & 7);
+    const int qb_log2 = 5 - rb_log2;
+    const int range = (rg << rb_log2) + (inner >> qb_log2);
+    const int qtile = (qg << qb_log2) + (inner & ((1 << qb_log2) - 1));
     if (range >= n_ranges || qtile >= q_tiles) return;   // whole workgroup leaves before any barrier
     const int m0 = qtile * SCAN2_QT;
     const int64_t n0 = (int64_t)range * SCAN2_RANGE;

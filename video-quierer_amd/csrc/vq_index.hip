@@ -271,8 +271,13 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
                     if (ver == 51) k5 = scan5_f16_top2_kernel<1>;
                     if (ver == 52) k5 = scan5_f16_top2_kernel<2>;
 #endif
-                    hipLaunchKernelGGL(k5, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
-                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys, x->dim);
+                    // workgroup -> (row range, query tile) blocking inside an XCD's 32 concurrent workgroups: $VQ_AMD_SCAN_RB = log2 of the
+                    // ranges per block (default 2: 4 ranges x 8 query tiles)
+                    static int rb = -1;
+                    if (rb < 0) { const char* e = getenv("VQ_AMD_SCAN_RB"); rb = e ? std::min(5, std::max(0, atoi(e))) : 2; }
+                    const int rg5 = cdiv(ranges, 1 << rb), qg5 = cdiv(q_tiles, 32 >> rb);
+                    hipLaunchKernelGGL(k5, dim3(rg5 * qg5 * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
+                                       x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, rg5, q_pad, x->d_keys, x->dim, rb);
                 } else if (ver == 4)
                     hipLaunchKernelGGL(scan4_f16_top2_kernel, dim3(range_groups * q_groups * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
                                        x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, range_groups, q_pad, x->d_keys);
