@@ -822,7 +822,10 @@ def test_sharded_search_at_the_scale_config_geometry(gpu_lib):
 @pytest.mark.timeout(180)
 def test_native_comm_world_of_one_over_rccl(gpu_lib):
     """vq_comm_* with a real RCCL communicator of one rank (all a one-GPU box can hold): the all-gather of rows is the
-    identity, ragged counts included, and the sharded search returns the single-index answer with global ids."""
+    identity and the sharded search returns the single-index answer with global ids.  What ONE rank cannot reach: the ragged
+    branch of vq_allgather_rows (pad, gather, compact — counts differ only between ranks) and ncclCommInitRank across processes;
+    RCCL refuses two ranks on one device, so those first run on the driver's multi-GPU node (bench.py gives that bring-up a
+    deadline and a torch-exchange relaunch)."""
     from video_quierer_amd.comm import Comm
     import socket
     import torch.distributed as dist
