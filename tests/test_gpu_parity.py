@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracles and the
 golden vectors.  Run on the MI355X box with `-m gpu`."""
 import os
+import sys
 import pickle
 
 import numpy as np
@@ -954,6 +955,23 @@ def test_search_large_k_and_tiny_batches(gpu_lib, b32_weights):
     ref = clip_vit_oracle.encode_frames(f, b32_weights, batch_size=1)
     assert np.sum(one_by_one * ref, axis=1).min() >= 1 - COS_TOL
     enc.close()
+
+
+def test_bench_config4_workload_on_one_gpu(gpu_lib):
+    """`bench.py --workload config4` = configs[3] end to end (4 x 1000 frames -> encode -> [all-gather] -> index under string ids ->
+    1,000 queries, k = 10) as the driver would type it for one GPU: one JSON line, every query finds its source frame first."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config4", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["frames_per_rank"] == [4000] and out["config"]["queries_per_rank"] == 1000
+    assert out["value"] > 0 and out["queries_per_s"] > 0 and out["last_job"]["top1_is_source_frame"] >= 0.99
 
 
 # ------------------------------------------------------------------ other geometries (streaming attention, patch 14)

@@ -26,7 +26,9 @@
 #include "gemm_mfma256w4.h"
 #include "gemm_mfma256d.h"
 #include "gemm_mfma128x256.h"
+#ifdef VQ_GEMM_EXPERIMENTS
 #include "gemm_mfma128x256p.h"
+#endif
 #include "gemm_mfma256f.h"
 
 namespace vq {
@@ -312,9 +314,14 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                             int M, int N, int K, const Epi& epi, int force = 0) {
     // 20 / 21: persistent out-of-phase 128x256 tiles, two workgroups per CU (gemm_mfma128x256p.h), on every shape that tiles
     // (20: the second workgroup of a CU starts half a tile late; 21: no lag — the in-step control of the A/B)
+#ifdef VQ_GEMM_EXPERIMENTS
     if ((force == 20 || force == 21) && M % GP_BM == 0 && N % GP_BN == 0 && K % (2 * GP_SUB_K) == 0 && K >= 4 * GP_SUB_K)
         return launch_gemm_tn128x256p<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, force == 20 ? 1 : 0, gp_dephase_cycles(K));
     if (force == 20 || force == 21) force = 6;
+#else       // measured and rejected (DESIGN.md §4 "Round 3"): not part of the product library
+    if (force == 20 || force == 21)
+        return fail(VQ_ERR_INVALID, "gemm kernel %d is an experiment: rebuild with `make EXPERIMENTS=1`", force);
+#endif
     // 12: 128x256 tiles, two workgroups per CU, wherever the 256x256 kernel would run (13: on every shape that tiles)
 #ifdef VQ_GEMM_EXPERIMENTS
     if ((force == 12 || force == 13) && M % G12_BM == 0 && N % G12_BN == 0 && K % (2 * G12_SUB_K) == 0 && K >= 4 * G12_SUB_K &&
