@@ -1,22 +1,24 @@
 // Fourth-generation batch scan: scan4_f16_top2_kernel (knn_scan_deep.h) with the top-2 fold taken OUT of the row-tile
 // boundary and spread behind the MFMA clusters that follow it.
 //
-// What scan4 paid (two geometries of one binary): a K-tile costs 2.58k cycles and a row tile carries 9.7k cycles
-// of fixed cost — a third of the 512-d tile.  That fixed part was the fold: per lane 128 scores x {and, or, med3, max, clear}
-// = 640 vector instructions in two bursts (behind phase 4 of a row tile's last K-tile and phase 1 of the next one), each
-// burst issued by a lone wave at one instruction per 4 cycles while its partner wave and the other wave group sat at the
-// barrier — and the two wave groups run one barrier apart, so their bursts came one after the other.
+// What the fold costs (measured, profiles/r03_scan_fold_ab.txt — NOT the "third of the kernel" round 2 inferred from two
+// geometries): scan4, which folds in two bursts per row tile (behind phase 4 of its last K-tile and phase 1 of the next one,
+// 640 vector instructions per lane and row tile: and, or, med3, max, clear per score), 9.79-9.83 ms; this mainloop with no fold
+// in the loop 9.12 (DIAG = 1); with the fold after each cluster, not interleaved, 9.69 (DIAG = 2); as built here 9.53-9.55.
 //
-// Here, per score: v_and_or_b32 (index bits in), v_med3_f32 (second key), v_med3_f32 against a large finite constant
-// (first key: a max the compiler cannot fold back into the canonicalising form) and the clear = 4 instructions.  (Starting a
-// row tile from the MFMA's C = 0 operand instead of clearing needs a second copy of every K-tile body; with it the register
-// allocator spilled ~100 registers across the merge points, so the clear stays.)  A finished quadrant's accumulators stay
-// untouched until that quadrant's own cluster of the next row tile's first K-tile, i.e. for the three clusters in between;
-// its 128 fold instructions are dealt over those clusters in units of one 16-row block (32 instructions), 2 or 3 blocks per
-// cluster, and interleaved with the cluster's 16 MFMAs (sched_group_barrier: one MFMA, then the cluster's share of vector
-// instructions).  An MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants), so
-// four or five 4-cycle instructions per MFMA stretch such a cluster from 256 to ~400 cycles — on six of a row tile's
-// 32 clusters — instead of adding two ~1,500-cycle bursts per wave group.
+// Here, per score: v_and_or_b32 (index bits in, mask in a VGPR so the index can be the one scalar operand), v_med3_f32 (second
+// key), v_med3_f32 against a large finite constant (first key: a max the compiler cannot fold back into the canonicalising
+// form) = 3 instructions, and no clear: the first K-tile of a row tile starts its accumulators from the MFMA's C = 0 operand
+// (template ZEROC; with the clear kept, 4 per score, the kernel measures the same: 9.37-9.40 against 9.36-9.41 ms).  A finished
+// quadrant's accumulators stay untouched until that quadrant's own cluster of the next row tile's first K-tile, i.e. for the
+// three clusters in between; its 96 fold instructions are dealt over those clusters in units of one 16-row block (24
+// instructions), 2 or 3 blocks per cluster, and placed BY HAND behind the cluster's 16 MFMAs: after each MFMA one or two scores,
+// pinned by sched_barrier(0) — an MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle
+// constants), so 3-6 four-cycle instructions per MFMA stretch such a cluster a little, on six of a row tile's 32 clusters.
+// (sched_group_barrier kept all three blocks' temporaries live across the cluster: 59 spills.)  Every K-tile variant — first /
+// inside / last of a row tile — is its own straight-line body: conditional copies of a cluster meet in phi nodes over the 32
+// accumulators they write and the allocator then spills INTO the K loop.  Row tile 0's first K-tile "folds" accumulators that
+// were pre-set to the masked sentinel, so there is no t == 0 copy either.
 //
 //   cluster (phase)            multiplies     folds (quadrant: 16-row blocks)
 //   last K-tile, phase 2       (0,1)          (0,0): 0 1 2
@@ -48,7 +50,8 @@ struct FoldSpec {
     static constexpr int hn(int s) { return s == 0 ? H0 : s == 1 ? H1 : H2; }
 };
 
-template <int DIAG /* 0 = product; diagnostic builds: 1 = no fold at all (keys invalid), 2 = fold not interleaved (after the cluster) */>
+template <int DIAG /* 0 = product; diagnostic builds: 1 = no fold at all (keys invalid), 2 = fold not interleaved (after the cluster) */,
+          bool ZEROC = true /* a row tile's first K-tile multiplies into the MFMA's C = 0 operand and the fold does not clear */>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __restrict__ X16,
                            int dim, int64_t n_valid, int q_tiles, int n_ranges, int range_groups, int64_t q_pad,
@@ -154,7 +157,7 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         const float kf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & keep_mask) | idx);
         p.y = __builtin_amdgcn_fmed3f(p.x, p.y, kf);
         p.x = __builtin_amdgcn_fmed3f(p.x, kf, BIG);
-        acc[mi][ni][r] = 0.f;
+        if constexpr (!ZEROC) acc[mi][ni][r] = 0.f;
     };
     auto fold_block = [&](auto ragged_tag, int mi, int hn, int t, float2& p) __attribute__((always_inline)) {
 #pragma unroll
@@ -167,35 +170,36 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     };
 #define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-    auto mfmas = [&](int hm, int hn) __attribute__((always_inline)) {
+    // one MFMA of a cluster (m = ks*8 + i*2 + j); `fresh`: the first K-tile of a row tile starts from C = 0
+    auto mfma1 = [&](auto fresh_tag, int hm, int hn, int m) __attribute__((always_inline)) {
+        const int ks = m >> 3, i = (m >> 1) & 3, j = m & 1;
+        f32x4& c = acc[hm * 4 + i][hn * 2 + j];
+        if (decltype(fresh_tag)::value && ks == 0) c = op::run(wf[hn][j][ks], af[i][ks], f32x4{0.f, 0.f, 0.f, 0.f});
+        else                                       c = op::run(wf[hn][j][ks], af[i][ks], c);
+    };
+    auto mfmas = [&](auto fresh_tag, int hm, int hn) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+        for (int m = 0; m < 16; ++m) mfma1(fresh_tag, hm, hn, m);
     };
     // 16 MFMAs of quadrant (hm, hn) with the fold blocks of `spec` (row tile ft) dealt between them BY HAND: after MFMA m come
     // the scores [m * Q / 16, (m + 1) * Q / 16) of the cluster's Q = 8 N (one or two: 4 or 8 vector instructions in a 16-cycle
     // MFMA shadow of which the MFMA itself holds the issue port for 8), pinned by sched_barrier(0) on both sides.  One block's
     // running pair is live at a time: it is read from LDS one MFMA before its first score and written back after its last.
     // (Left to sched_group_barrier the same work kept all three pairs and their temporaries live across the cluster: 59 spills.)
-    auto cluster_fold = [&](auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
+    auto cluster_fold = [&](auto fresh_tag, auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
         typedef decltype(spec) S;
         constexpr int Q = S::N * 8;
         float2 p[3];
         p[0] = mm[S::mi(0) * 64];
         if constexpr (DIAG == 2) {
-            mfmas(hm, hn);
+            mfmas(fresh_tag, hm, hn);
 #pragma unroll
             for (int s = 0; s < 3; ++s) if (s < S::N) { if (s) p[s] = mm[S::mi(s) * 64]; fold_block(ragged_tag, S::mi(s), S::hn(s), ft, p[s]); mm[S::mi(s) * 64] = p[s]; }
             return;
         }
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const int ks = m >> 3, i = (m >> 1) & 3, j = m & 1;
-            acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
+            mfma1(fresh_tag, hm, hn, m);
             __builtin_amdgcn_sched_barrier(0);
             const int q0 = m * Q / 16, q1 = (m + 1) * Q / 16;
             // the pair of the block that starts in the NEXT gap
@@ -211,11 +215,11 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto cluster = [&](auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
+    auto cluster = [&](auto fresh_tag, auto ragged_tag, int hm, int hn, auto spec, int ft) __attribute__((always_inline)) {
         typedef decltype(spec) S;
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (DIAG == 1 || S::N == 0) mfmas(hm, hn);
-        else cluster_fold(ragged_tag, hm, hn, spec, ft);
+        if constexpr (DIAG == 1 || S::N == 0) mfmas(fresh_tag, hm, hn);
+        else cluster_fold(fresh_tag, ragged_tag, hm, hn, spec, ft);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -225,6 +229,7 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     // nodes over the 32 accumulators they write, and the register allocator then spills (measured: 15-77 registers).
     auto tile = [&](auto kind_tag, auto ragged_tag, int kt, int bufi, int t, int kk) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_tag)::value;
+        const std::integral_constant<bool, KIND == 1 && ZEROC && DIAG != 1> fresh{};
         const char* buf = smem + bufi * G2_BUF;
         const bool next = kt + 1 < total, next2 = kt + 2 < total;
         const int kk1 = kk + 1 == nk ? 0 : kk + 1, t1 = kk + 1 == nk ? t + 1 : t;
@@ -235,8 +240,8 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         else      { VQ_VMCNT(2); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (KIND == 1) cluster(ragged_tag, 0, 0, FoldSpec<3, 4, 1, 5, 1, 6, 1>{}, t - 1);       // (1,1): 0 1 2
-        else                     cluster(ragged_tag, 0, 0, FoldSpec<0>{}, t);
+        if constexpr (KIND == 1) cluster(fresh, ragged_tag, 0, 0, FoldSpec<3, 4, 1, 5, 1, 6, 1>{}, t - 1);       // (1,1): 0 1 2
+        else                     cluster(fresh, ragged_tag, 0, 0, FoldSpec<0>{}, t);
         barrier();
         // phase 2: quadrant (0,1)
         load_w(buf, 1);
@@ -244,25 +249,25 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
         else      { VQ_VMCNT(0); }
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (KIND == 2)      cluster(ragged_tag, 0, 1, FoldSpec<3, 0, 0, 1, 0, 2, 0>{}, t);      // (0,0): 0 1 2
-        else if constexpr (KIND == 1) cluster(ragged_tag, 0, 1, FoldSpec<3, 7, 1, 4, 0, 5, 0>{}, t - 1);  // (1,1): 3   (1,0): 0 1
-        else                          cluster(ragged_tag, 0, 1, FoldSpec<0>{}, t);
+        if constexpr (KIND == 2)      cluster(fresh, ragged_tag, 0, 1, FoldSpec<3, 0, 0, 1, 0, 2, 0>{}, t);      // (0,0): 0 1 2
+        else if constexpr (KIND == 1) cluster(fresh, ragged_tag, 0, 1, FoldSpec<3, 7, 1, 4, 0, 5, 0>{}, t - 1);  // (1,1): 3   (1,0): 0 1
+        else                          cluster(fresh, ragged_tag, 0, 1, FoldSpec<0>{}, t);
         barrier();
         // phase 3: quadrant (1,1)
         load_a(buf, 1);
         if (next2) stage_a(bufi, 0, kk2);
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (KIND == 2)      cluster(ragged_tag, 1, 1, FoldSpec<3, 3, 0, 0, 1, 1, 1>{}, t);      // (0,0): 3   (0,1): 0 1
-        else if constexpr (KIND == 1) cluster(ragged_tag, 1, 1, FoldSpec<2, 6, 0, 7, 0>{}, t - 1);        // (1,0): 2 3
-        else                          cluster(ragged_tag, 1, 1, FoldSpec<0>{}, t);
+        if constexpr (KIND == 2)      cluster(fresh, ragged_tag, 1, 1, FoldSpec<3, 3, 0, 0, 1, 1, 1>{}, t);      // (0,0): 3   (0,1): 0 1
+        else if constexpr (KIND == 1) cluster(fresh, ragged_tag, 1, 1, FoldSpec<2, 6, 0, 7, 0>{}, t - 1);        // (1,0): 2 3
+        else                          cluster(fresh, ragged_tag, 1, 1, FoldSpec<0>{}, t);
         barrier();
         // phase 4: quadrant (1,0): no fragment reads
         if (next2)     { stage_w(bufi, 0, t2, kk2); VQ_VMCNT(8); }
         else if (next) { VQ_VMCNT(4); }
         barrier();
-        if constexpr (KIND == 2) cluster(ragged_tag, 1, 0, FoldSpec<2, 2, 1, 3, 1>{}, t);                 // (0,1): 2 3
-        else                     cluster(ragged_tag, 1, 0, FoldSpec<0>{}, t);
+        if constexpr (KIND == 2) cluster(fresh, ragged_tag, 1, 0, FoldSpec<2, 2, 1, 3, 1>{}, t);                 // (0,1): 2 3
+        else                     cluster(fresh, ragged_tag, 1, 0, FoldSpec<0>{}, t);
         barrier();
     };
 

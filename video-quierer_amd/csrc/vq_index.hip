@@ -234,6 +234,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 #ifdef VQ_DIAG
             VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN4_LDS_BYTES));
             VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN4_LDS_BYTES));
+            VQ_HIP(hipFuncSetAttribute((const void*)scan5_f16_top2_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN4_LDS_BYTES));
 #endif
             attr_set = true;
         }
@@ -270,6 +271,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 #ifdef VQ_DIAG
                     if (ver == 51) k5 = scan5_f16_top2_kernel<1>;
                     if (ver == 52) k5 = scan5_f16_top2_kernel<2>;
+                    if (ver == 53) k5 = scan5_f16_top2_kernel<0, false>;      // the fold clears its accumulators (no C = 0 MFMAs)
 #endif
                     // workgroup -> (row range, query tile) blocking inside an XCD's 32 concurrent workgroups: $VQ_AMD_SCAN_RB = log2 of the
                     // ranges per block (default 2: 4 ranges x 8 query tiles)
@@ -372,7 +374,7 @@ int vq_index_create(int dim, vq_index** out) {
     VQ_CHECK(out && dim > 0 && dim % 4 == 0 && dim <= 4096, "vq_index_create: dim %d must be a positive multiple of 4", dim);
     vq_index* x = new vq_index();
     x->dim = dim;
-    if (const char* sv = getenv("VQ_AMD_SCAN")) { const int v = atoi(sv); x->scan_version = (v == 1 || v == 2 || v == 4 || v == 51 || v == 52) ? v : 5; }
+    if (const char* sv = getenv("VQ_AMD_SCAN")) { const int v = atoi(sv); x->scan_version = (v == 1 || v == 2 || v == 4 || v == 51 || v == 52 || v == 53) ? v : 5; }
     if (dim % 128 != 0) x->scan_version = 1;
     if (const char* ss = getenv("VQ_AMD_SCAN_SMALL")) x->no_small_scan = atoi(ss) == 0;
     hipError_t e = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
