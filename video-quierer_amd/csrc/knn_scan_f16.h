@@ -486,6 +486,12 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
     __shared__ int state[QPW];
     __shared__ float qn2[QPW][SHARES];                   // partial |q|^2 (the bound scales with |q|)
     __shared__ float dk_s[QPW];                             // k-th smallest exact distance among the candidates
+    constexpr int LMAX = 4 * C;                                // collected keys per query in step 2
+    static_assert(LMAX <= POOL, "the collected list lives in the candidate arrays");
+    float (*sel_v)[POOL] = cand_dist;                          // step 2's list: in the candidate arrays, which step 3 writes first
+    int (*sel_i)[POOL] = cand_row;                             // (8-10 KB of LDS of its own cost the <8, 6, 32> form a workgroup per CU)
+    __shared__ int sel_n[QPW];
+    __shared__ float thr1[QPW];
 
     const int tid = threadIdx.x;
     const int ql = tid % QPW, share = tid / QPW;
@@ -558,9 +564,16 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
     if (tid < QPW) { pool_n[tid] = 0; resc_n[tid] = 0; state[tid] = 0; }
     __syncthreads();
 
-    // ---- 2. per query (one 16-lane group each): the best C of the 128 kept keys, by rank counting ----
-    //      rank(i) = #{j : v_j > v_i or (v_j == v_i and j < i)}; unique ranks 0..127
-    {
+    // ---- 2. per query (TPQ threads each): the best C of the SHARES * KEEP kept keys and the (C+1)-th as a bound ----
+    // C <= 32: rank counting over all kept keys, rank(i) = #{j : v_j > v_i or (v_j == v_i and j < i)} — 1,152 steps per thread
+    // at <8, 6, 32>.  At <4, 10, 80> that would be 6,400 (80 us of a single large-k query), so two levels instead, same order,
+    // same result:  (a) T1 = the (C+1)-th largest among the FIRST P keys of every share (P = ceil((C+1) / SHARES); a share's
+    // list is sorted, so these are its P largest): at least C+1 kept keys reach T1, hence every one of the best C+1 does;
+    // (b) the keys >= T1 (a few more than C+1) are collected;  (c) and ranked among themselves by (value desc, slot asc).  More
+    // collected keys than the list holds (runs of equal keys) -> nothing is proven for that query: state 2, exact fallback.
+    // (On the 32-candidate form the two-level selection measured no faster — three more barriers and LDS atomics — and stays off.)
+    if constexpr (C <= 32) {
+        if (tid < QPW) sel_n[tid] = 0;
         const int qq = tid / TPQ, l16 = tid % TPQ;       // TPQ threads per query here
         for (int i = l16; i < SHARES * KEEP; i += TPQ) {
             const float vi = kept_v[qq][i];
@@ -572,8 +585,46 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
             if (rank < C) { cand_key[qq][rank] = vi; cand_src[qq][rank] = kept_s[qq][i]; }
             if (rank == C) bound_rest[qq] = vi;
         }
+        __syncthreads();
+    } else {
+        constexpr int P = (C + 1 + SHARES - 1) / SHARES;
+        static_assert(P <= KEEP && SHARES * P >= C + 1, "the first P keys of every share must hold C+1 keys");
+        const int qq = tid / TPQ, l16 = tid % TPQ;       // TPQ threads per query here
+        for (int c = l16; c < C; c += TPQ) { cand_key[qq][c] = NEG; cand_src[qq][c] = -1; }
+        if (l16 == 0) { bound_rest[qq] = NEG; sel_n[qq] = 0; thr1[qq] = NEG; }
+        __syncthreads();
+        for (int e = l16; e < SHARES * P; e += TPQ) {
+            const float vi = kept_v[qq][(e / P) * KEEP + (e % P)];
+            int rank = 0;
+            for (int f = 0; f < SHARES * P; ++f) {
+                const float vf = kept_v[qq][(f / P) * KEEP + (f % P)];
+                rank += (vf > vi) || (vf == vi && f < e);
+            }
+            if (rank == C) thr1[qq] = vi;                     // ranks are a permutation: one writer
+        }
+        __syncthreads();
+        const float t1 = thr1[qq];
+        for (int i = l16; i < SHARES * KEEP; i += TPQ) {
+            const float vi = kept_v[qq][i];
+            if (vi >= t1 && vi > NEG) {
+                const int pos = atomicAdd(&sel_n[qq], 1);
+                if (pos < LMAX) { sel_v[qq][pos] = vi; sel_i[qq][pos] = i; }
+            }
+        }
+        __syncthreads();
+        const int ns = min(sel_n[qq], LMAX);
+        for (int e = l16; e < ns; e += TPQ) {
+            const float vi = sel_v[qq][e]; const int ii = sel_i[qq][e];
+            int rank = 0;
+            for (int f = 0; f < ns; ++f) {
+                const float vf = sel_v[qq][f];
+                rank += (vf > vi) || (vf == vi && sel_i[qq][f] < ii);
+            }
+            if (rank < C) { cand_key[qq][rank] = vi; cand_src[qq][rank] = kept_s[qq][ii]; }
+            if (rank == C) bound_rest[qq] = vi;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- 3. exact re-score of the candidates: thread (query, c) for c = share, share+16 ----
     const bool q_live = q < nq;
@@ -626,7 +677,7 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
         int st = 0;
         const bool all_rows_scored = n_valid <= 0;
         (void)all_rows_scored;
-        if (have < kk || !(q2 >= SCAN_Q2_MIN && q2 <= SCAN_Q2_MAX)) {
+        if (have < kk || !(q2 >= SCAN_Q2_MIN && q2 <= SCAN_Q2_MAX) || sel_n[qq] > LMAX) {
             st = 2;                                            // fewer than k distinct rows among the candidates, or a query the fp16 bound does not cover
         } else {
             if (!(bound_rest[qq] + SCAN_EPS < sk)) st = 2;     // kept keys outside the best C could still matter
@@ -653,6 +704,10 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
         if (state[qq] != 1) continue;                           // block-uniform (LDS value)
         const int nres = resc_n[qq];
         const float* qv2 = queries + (size_t)(q0 + qq) * dim;
+        // candidates of a re-scanned stream leave the pool (the stream's rows are all in it now): pool rows stay distinct
+        for (int c = tid; c < C; c += 256)
+            if (cand_row[qq][c] >= 0)
+                for (int w = 0; w < nres; ++w) if ((cand_src[qq][c] >> 1) == resc_stream[qq][w]) cand_row[qq][c] = -1;
         for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
             const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
             const int64_t r = layout == 3 ? scan3_row_of(resc_stream[qq][which], local)
@@ -665,8 +720,10 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
     }
     __syncthreads();
 
-    // ---- 6. final exact top-k of the pool by (distance, row); duplicates collapse (same key) ----
-    {
+    // ---- 6. final exact top-k of the pool by (distance, row).  C <= 32: k rounds of "smallest key above the previous one"
+    //         (a shuffle tree per round; duplicates would collapse).  Larger pools: rank counting — pool rows are distinct (step 5),
+    //         so ranks are a permutation; the k rounds cost 21 us of a single query at k = 40 ----
+    if constexpr (C <= 32) {
         const int qq = tid / TPQ, l16 = tid % TPQ;
         if (q0 + qq < nq) {
             const int pn = pool_n[qq];
@@ -696,6 +753,23 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
                     }
                     break;
                 }
+            }
+        }
+    } else {
+        const int qq = tid / TPQ, l16 = tid % TPQ;
+        if (q0 + qq < nq) {
+            const int pn = pool_n[qq];
+            if (l16 == 0) flags[q0 + qq] = state[qq];
+            int valid = 0;
+            for (int i = 0; i < pn; ++i) valid += cand_row[qq][i] >= 0;                  // same count in every thread of the query
+            for (int j = valid + l16; j < k; j += TPQ) { out_ids[(size_t)(q0 + qq) * k + j] = -1; out_dist[(size_t)(q0 + qq) * k + j] = __builtin_inff(); }
+            for (int i = l16; i < pn; i += TPQ) {
+                if (cand_row[qq][i] < 0) continue;
+                const uint64_t ki = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
+                int rank = 0;
+                for (int j = 0; j < pn; ++j)
+                    rank += cand_row[qq][j] >= 0 && dist_key(cand_dist[qq][j], (uint32_t)cand_row[qq][j]) < ki;
+                if (rank < k) { out_ids[(size_t)(q0 + qq) * k + rank] = cand_row[qq][i]; out_dist[(size_t)(q0 + qq) * k + rank] = cand_dist[qq][i]; }
             }
         }
     }
