@@ -23,7 +23,31 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 # with the caller's own streams and the copy streams; measured on one MI355X: two handles 82k frames/s with 4 queues, 100k with
 # 8 (three handles: 99k / 100k).  The runtime reads it when it initialises, so this only takes effect when the package is imported
 # before the process's first HIP call; a value the caller exported wins.
+_HWQ_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def _warn_if_hip_started_first() -> None:
+    """The variable above is read when the HIP runtime starts.  If this process had already initialised HIP (torch.cuda in use
+    before this package was imported) and had not exported the variable itself, the default of 4 hardware queues is in force
+    and encoder handles on separate streams overlap poorly (two handles: ~82k instead of ~100k frames/s): say so once."""
+    import sys
+    if _HWQ_PRESET is not None:
+        return
+    torch = sys.modules.get("torch")
+    try:
+        started = bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:                        # noqa: BLE001 - advisory only
+        started = False
+    if started:
+        import warnings
+        warnings.warn("video_quierer_amd was imported after this process had initialised HIP: GPU_MAX_HW_QUEUES=8 could not take "
+                      "effect (the runtime keeps its 4 hardware queues) and batches in flight on separate streams will overlap "
+                      "poorly.  Export GPU_MAX_HW_QUEUES=8 before the process's first HIP call, or import this package first.",
+                      RuntimeWarning, stacklevel=3)
+
+
+_warn_if_hip_started_first()
 
 ENC_NCLASS = 11
 IDX_NCLASS = 6
