@@ -442,6 +442,23 @@ def main():
             dist.destroy_process_group()
         return
 
+    if comm is not None:
+        # the FIRST all-gather through the library's communicator has never run anywhere before the driver's multi-GPU node:
+        # one step + fence against the same deadline as the bring-up; a rank stuck in it leaves with RELAUNCH_CODE and the
+        # supervisors relaunch with the torch exchange (every rank's deadline expires together: they all wait in this fence)
+        import threading
+        first_done = threading.Event()
+
+        def first_step_watchdog():
+            if not first_done.wait(float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120"))):
+                sys.stderr.write(f"bench.py[rank {rank}]: the first native all-gather did not complete in time\n")
+                sys.stderr.flush()
+                os._exit(RELAUNCH_CODE)
+
+        threading.Thread(target=first_step_watchdog, daemon=True).start()
+        step(0)
+        fence()
+        first_done.set()
     for i in range(args.warmup):
         step(i)
     fence()
