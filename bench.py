@@ -442,23 +442,27 @@ def main():
             dist.destroy_process_group()
         return
 
-    if comm is not None:
-        # the FIRST all-gather through the library's communicator has never run anywhere before the driver's multi-GPU node:
-        # one step + fence against the same deadline as the bring-up; a rank stuck in it leaves with RELAUNCH_CODE and the
-        # supervisors relaunch with the torch exchange (every rank's deadline expires together: they all wait in this fence)
+    def first_native_call(what, fn):
+        """The library's collectives have never run across processes before the driver's multi-GPU node: the FIRST call of each
+        (+ a fence) runs against the same deadline as the bring-up; a rank stuck in it leaves with RELAUNCH_CODE and the
+        supervisors relaunch with the torch exchange (every rank's deadline expires together: they all wait in that fence)."""
+        if comm is None:
+            return
         import threading
-        first_done = threading.Event()
+        done = threading.Event()
 
-        def first_step_watchdog():
-            if not first_done.wait(float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120"))):
-                sys.stderr.write(f"bench.py[rank {rank}]: the first native all-gather did not complete in time\n")
+        def watchdog():
+            if not done.wait(float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120"))):
+                sys.stderr.write(f"bench.py[rank {rank}]: the first native {what} did not complete in time\n")
                 sys.stderr.flush()
                 os._exit(RELAUNCH_CODE)
 
-        threading.Thread(target=first_step_watchdog, daemon=True).start()
-        step(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        fn()
         fence()
-        first_done.set()
+        done.set()
+
+    first_native_call("all-gather of embeddings", lambda: step(0))
     for i in range(args.warmup):
         step(i)
     fence()
@@ -611,6 +615,7 @@ def main():
             fence()
             return max_over_ranks(time.perf_counter() - t0) / reps
 
+        first_native_call("sharded search (all-gather of keys + merge)", lambda: search_step(nq))
         s_batch = timed_search(3, nq)
         qps = nq / s_batch
         flops = 2.0 * nq * n_rows * world * dimq
