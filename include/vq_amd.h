@@ -207,7 +207,7 @@ int vq_index_clear(vq_index* idx);
  * fp16 path's exactness bound scales with each query's own norm while 0.25 <= |q|^2 <= 4; a query outside that
  * range (or not finite) is outside what fp16 operands can bound and is answered by the exact scan instead
  * (device-side fallback), so un-normalised queries stay exact at any scale.  ids/dist are [nq][k]; unused slots
- * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 64: the caller over-fetches k * 2, video_search_system.py:297), 1 exact
+ * (k > size) are id -1 / dist +inf.  mode: 0 auto (fp16 scan from 16,384 rows and k <= 100: the API takes k up to 50, src/api/routes.py:58, and the caller searches for k * 2, video_search_system.py:297), 1 exact
  * fp32-master scan, 2 fp16 MFMA scan + exact re-score with proof (unproven queries are redone by the
  * exact scan, on the device: nothing is read back).  vq_index_search_device is asynchronous on the index's
  * stream in every mode, with one exception: the first search after a vq_index_add_device(normalize=0) waits

@@ -934,21 +934,21 @@ def test_search_large_k_and_tiny_batches(gpu_lib, b32_weights):
     from video_quierer_amd.weights import VIT_B_32
     rng = np.random.default_rng(41)
     vecs = rng.standard_normal((17000, 512)).astype(np.float32)
-    idx = _mk_index(vecs)                                        # auto mode: > 16384 rows -> fp16 scan when k <= 64
+    idx = _mk_index(vecs)                                        # auto mode: > 16384 rows -> fp16 scan when k <= 100
     qs = rng.standard_normal((5, 512)).astype(np.float32)
     stored = idx._export()
     uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
-    for k in (33, 64, 65, 100):                                  # 33, 64: the fp16 scan's wide pool; beyond 64 -> exact scan
+    for k in (33, 64, 65, 100, 101, 150):                        # up to 100 (the API's k <= 50, doubled by the caller): the fp16 scans' wide pools; beyond -> exact scan
         res = idx.search_batch(list(qs), k)
         oid, od = knn_oracle.topk(stored, uq, k)
         assert np.array_equal(np.array([[r["id"] for r in rr] for rr in res]), oid)
         assert np.array_equal(np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32), od)
         st = idx.last_search_stats()
-        assert k <= 64 or st["exact_fallback"] == 5, (k, st)      # beyond 64: the exact scan answers every query
+        assert k <= 100 or st["exact_fallback"] == 5, (k, st)     # beyond 100: the exact scan answers every query
     idx.search_mode = MODE_FP16
-    assert len(idx.search(qs[0], 64)) == 64
+    assert len(idx.search(qs[0], 64)) == 64 and len(idx.search(qs[0], 100)) == 100
     with pytest.raises(ValueError):
-        idx.search(qs[0], 65)
+        idx.search(qs[0], 101)
     enc = VitEncoder(VIT_B_32, b32_weights, max_batch=1)        # smallest workspace, one frame at a time
     f = synth_frames(3, seed=2)
     one_by_one = enc.encode(f)
@@ -1101,8 +1101,8 @@ def test_config3_full_size_properties(gpu_lib):
         assert torch.equal(a_i, b_i) and torch.equal(a_d, b_d), nq
         assert st["verified"] + st["rescanned"] + st["exact_fallback"] == nq and st["exact_fallback"] <= 1, (nq, st)
     # the caller's over-fetch (k * 2, video_search_system.py:297) for user k up to 32: k in (20, 64] stays on the fp16 scans
-    # (80-candidate re-score pool) and closes its proofs at this size — 0 or 1 query through the exact fallback
-    for nq, k in ((1, 20), (1, 32), (1, 64), (33, 24), (300, 32), (300, 64)):
+    # (80- / 128-candidate re-score pools up to k = 100: the API's k <= 50) and closes its proofs at this size
+    for nq, k in ((1, 20), (1, 32), (1, 64), (33, 24), (300, 32), (300, 64), (1, 100), (300, 100)):
         a_i = torch.empty((nq, k), dtype=torch.int32, device=dev); a_d = torch.empty((nq, k), device=dev)
         b_i = torch.empty((nq, k), dtype=torch.int32, device=dev); b_d = torch.empty((nq, k), device=dev)
         idx.search_device(more.data_ptr(), nq, k, a_i.data_ptr(), a_d.data_ptr(), mode=MODE_FP16); idx.synchronize()

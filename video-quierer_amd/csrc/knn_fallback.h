@@ -20,7 +20,7 @@ namespace vq {
 constexpr int FB_QG = 8;          // flagged queries per row pass
 constexpr int FB_TILE = 256;      // rows per tile = threads per workgroup
 constexpr int FB_PANEL = 32;      // dims per LDS panel
-constexpr int FB_KMAX = 64;       // largest k of the fp16 path (RV_K_MAX)
+constexpr int FB_KMAX = 100;      // largest k of the fp16 path (RV_K_MAX); with the row tile and the candidate lists this fills the 64 KiB of static LDS
 constexpr int FB_SPLIT_ROWS = 2048;   // rows per workgroup of the bulk rounds
 constexpr int FB_FAST_ROWS = 512;     // ... of the first round (the first FB_FAST_SLOTS flagged queries: the normal case is a handful)
 constexpr int FB_FAST_SLOTS = 64;

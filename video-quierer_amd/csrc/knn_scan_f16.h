@@ -776,10 +776,14 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
 }
 
 // the instantiation round 2 shipped, under its old name
-constexpr int RV_K_SMALL = 20, RV_K_MAX = 64;
+// k <= 20: <8, 6, 32> (batches) / rescore_verify_small_kernel (<= 96 queries); k <= 64: <4, 10, 80>; k <= 100: <4, 12, 128> — the
+// reference's API takes k up to 50 (src/api/routes.py:58) and searches the index for k * 2 (video_search_system.py:297)
+constexpr int RV_K_SMALL = 20, RV_K_MID = 64, RV_K_MAX = 100;
 constexpr int RVL_QPW = 4, RVL_KEEP = 10, RVL_C = 80;
+constexpr int RVX_QPW = 4, RVX_KEEP = 12, RVX_C = 128;
 static const auto rescore_verify_kernel = rescore_verify_kernel_t<RV_QPW, RV_KEEP, RV_C>;
 static const auto rescore_verify_large_kernel = rescore_verify_kernel_t<RVL_QPW, RVL_KEEP, RVL_C>;
+static const auto rescore_verify_xlarge_kernel = rescore_verify_kernel_t<RVX_QPW, RVX_KEEP, RVX_C>;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small batches (nq <= SCAN3_MAX_Q, keys in layout 3): ONE workgroup per query instead of 16 queries per workgroup.

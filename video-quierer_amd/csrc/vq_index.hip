@@ -295,7 +295,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             Prof p(x, I_RESCORE);
             const bool large = k > RV_K_SMALL;                  // k in (20, 64]: the wide candidate pool, whatever scan produced the keys
             if (large)
-                hipLaunchKernelGGL(rescore_verify_large_kernel, dim3(cdiv(cur, RVL_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
+                hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge_kernel : rescore_verify_large_kernel, dim3(cdiv(cur, RVL_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                    q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
                                    d_dist_out + q0 * k, x->d_flags + q0, ver == 3 ? 3 : deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
             else if (ver == 3)
