@@ -222,6 +222,8 @@ int vq_index_set_stream(vq_index* idx, void* hip_stream);
 
 /* save / load support (hnsw.py:306-380): the stored (normalised) rows. */
 int vq_index_export(vq_index* idx, float* rows /*[size][dim]*/);
+/* Single stored rows (the reference reads `self.data[node_id]`, a dict lookup): out [n][dim] = rows row_numbers[0..n). */
+int vq_index_read_rows(vq_index* idx, const int64_t* row_numbers, int64_t n, float* out);
 
 /* ---- multi-GPU exchange over RCCL (xGMI): one process per GPU ------------------------------------
  * The reference is single-device; these entry points are what a multi-GPU deployment of its

@@ -714,6 +714,11 @@ def test_index_loads_a_file_written_by_the_reference(gpu_lib):
     idx.load(os.path.join(gdir, "ref_index_50.pkl"))
     assert idx.dimension == 64 and idx.size() == 50 and idx.M == 16 and idx.ef_search == 50
     assert idx.entry_point in ids and set(idx.data) == set(ids)
+    view = idx.data                                                     # hnsw.py:44 `self.data`: a read-only view of the device matrix
+    assert len(view) == len(ids) and ids[3] in view and "no such id" not in view
+    assert np.array_equal(view[ids[3]], idx._export()[3]) and np.array_equal(dict(view.items())[ids[0]], idx._export()[0])
+    with pytest.raises(KeyError):
+        view["no such id"]
     for i, q in enumerate(qs):
         res = idx.search(q, 5)
         assert [r["id"] for r in res] == list(gold["ids"][i])

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vq_index_synchronize": (c_int, [c_void_p]),
     "vq_index_set_stream": (c_int, [c_void_p, c_void_p]),
     "vq_index_export": (c_int, [c_void_p, POINTER(c_float)]),
+    "vq_index_read_rows": (c_int, [c_void_p, POINTER(c_int64), c_int64, POINTER(c_float)]),
     "vq_index_profile_begin": (c_int, [c_void_p]),
     "vq_index_profile_end": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
     "vq_index_profile_class_name": (c_char_p, [c_int]),

@@ -568,6 +568,19 @@ int vq_index_export(vq_index* x, float* rows) {
     return 0;
 }
 
+int vq_index_read_rows(vq_index* x, const int64_t* row_numbers, int64_t n, float* out) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && n >= 0 && (n == 0 || (row_numbers && out)), "vq_index_read_rows: bad argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    for (int64_t i = 0; i < n; ++i) {
+        VQ_CHECK(row_numbers[i] >= 0 && row_numbers[i] < x->size, "vq_index_read_rows: row %lld outside [0, %lld)",
+                 (long long)row_numbers[i], (long long)x->size);
+        VQ_HIP(hipMemcpyAsync(out + i * x->dim, x->rows + row_numbers[i] * x->dim, (size_t)x->dim * 4, hipMemcpyDeviceToHost, x->stream));
+    }
+    VQ_HIP(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
 int vq_index_profile_begin(vq_index* x) {
     VQ_CHECK(x, "vq_index_profile_begin: null handle");
     std::lock_guard<std::mutex> lk(x->mu);

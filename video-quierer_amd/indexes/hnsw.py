@@ -20,6 +20,7 @@ import os
 import pickle
 import threading
 import time
+from collections.abc import Mapping
 from concurrent.futures import ThreadPoolExecutor
 from ctypes import POINTER, c_float, c_int32, c_int64, c_void_p
 from typing import Dict, Hashable, List, Optional, Sequence
@@ -29,6 +30,39 @@ import numpy as np
 from video_quierer_amd import _lib
 
 MODE_AUTO, MODE_EXACT, MODE_FP16 = 0, 1, 2
+
+
+class _RowView(Mapping):
+    """Read-only ``id -> stored row`` view of an index (``HNSWIndex.data``)."""
+
+    def __init__(self, index):
+        self._index = index
+
+    def __len__(self):
+        return len(self._index._ids)
+
+    def __iter__(self):
+        return iter(self._index._ids)
+
+    def __contains__(self, node_id):
+        return node_id in self._index._row_of
+
+    def __getitem__(self, node_id):
+        idx = self._index
+        with idx.lock:
+            row = idx._row_of[node_id]                       # KeyError for an unknown id, as a dict would
+            out = np.empty((1, idx.dimension), dtype=np.float32)
+            rn = (ctypes.c_int64 * 1)(row)
+            _lib.check(_lib.load().vq_index_read_rows(idx._h, rn, 1, _lib.fptr(out)))
+        return out[0]
+
+    def items(self):
+        rows = self._index._export()
+        return [(i, rows[r]) for r, i in enumerate(self._index._ids)]
+
+    def values(self):
+        rows = self._index._export()
+        return [rows[r] for r in range(len(self._index._ids))]
 
 
 class HNSWIndex:
@@ -62,9 +96,11 @@ class HNSWIndex:
 
     # -- reference-shaped views of the state (hnsw.py:44-49) ---------------------
     @property
-    def data(self) -> Dict[Hashable, np.ndarray]:
-        rows = self._export()
-        return {i: rows[r] for r, i in enumerate(self._ids)}
+    def data(self) -> "Mapping[Hashable, np.ndarray]":
+        """The reference's ``self.data`` dict (id -> stored unit vector, hnsw.py:44) as a read-only view of the device matrix:
+        a lookup fetches that one row, iteration / ``len`` / ``in`` touch no device memory, ``items()`` / ``values()`` / ``dict(...)``
+        export the matrix once.  (Round 2 exported every row on every access.)"""
+        return _RowView(self)
 
     @property
     def levels(self) -> Dict[Hashable, int]:
@@ -271,7 +307,7 @@ class HNSWIndex:
                 "dimension": self.dimension, "M": self.M, "max_M": self.max_M,
                 "ef_construction": self.ef_construction, "ef_search": self.ef_search,
                 "level_generation_factor": self.level_generation_factor,
-                "data": self.data, "levels": self.levels, "graph": self.graph,
+                "data": dict(self.data.items()), "levels": self.levels, "graph": self.graph,
                 "entry_point": self.entry_point, "element_count": self.element_count,
                 "exact_index": True,     # extra key: no navigable graph in this file
             }
