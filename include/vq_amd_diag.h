@@ -31,7 +31,9 @@ int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz
 int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long* stamps);
 
 /* One GEMM kernel with one of the tower's epilogues, timed in isolation (fp16 operands, random data).
- * kernel: 8 = 256x256 deep prefetch, 20 = persistent out-of-phase 128x256 (two workgroups per CU), 12 = the
+ * kernel: 8 = 256x256 deep prefetch, 24 = the four-wave 256x256 kernel whose K loop is one hand-scheduled asm text
+ * (csrc/gemm_asm256.h; mode 0 = the product schedule, 1-5 = timing ablations of csrc/gemm_asm256_loop.inc; census: null or
+ * >= 2 entries that receive the median clock inside the K loop in MHz and the median K-loop cycles per workgroup), 20 = persistent out-of-phase 128x256 (two workgroups per CU), 12 = the
  * non-persistent 128x256 experiment (EXPERIMENTS builds).  epi: 0 = fp32 store, 1 = bias + residual + 16-bit copy +
  * LayerNorm row partials, 2 = LayerNorm-consuming quick-GELU 16-bit store, 3 = the same without GELU.
  * mode / dephase_cycles / grid: kernel 20 only (csrc/gemm_mfma128x256p.h).  census: null or [grid][4] =

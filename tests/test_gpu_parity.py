@@ -18,7 +18,7 @@ COS_TOL = 1e-3
 
 
 # ------------------------------------------------------------------ GEMM mainloop
-GEMM_KERNELS = [1, 2, 5, 8, 11, 16]  # (9 and 13 were measured and rejected: `make EXPERIMENTS=1` builds only, with 3, 4, 7, 10)  16 = deep-prefetch 256x256 with several tiles per workgroup (next tile's first K-tile lands under the epilogue); 13 = 128x256 tiles, 4 waves, 3-slot ring, two workgroups per CU; 9 = two phases of 32 MFMAs per K-tile (half the barriers), buffer_load..lds staging; 8 stages with buffer_load..lds, 11 = 8 with global_load_lds staging; 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave, 10 register-double-buffered ring: `make EXPERIMENTS=1` builds only)
+GEMM_KERNELS = [1, 2, 5, 8, 11, 16, 24]  # 24 = four waves, K loop scheduled by hand as one asm text (gemm_asm256.h)  (9 and 13 were measured and rejected: `make EXPERIMENTS=1` builds only, with 3, 4, 7, 10)  16 = deep-prefetch 256x256 with several tiles per workgroup (next tile's first K-tile lands under the epilogue); 13 = 128x256 tiles, 4 waves, 3-slot ring, two workgroups per CU; 9 = two phases of 32 MFMAs per K-tile (half the barriers), buffer_load..lds staging; 8 stages with buffer_load..lds, 11 = 8 with global_load_lds staging; 1 = 128x128, 2 = 256x256 four-phase, 5 = 160x256 ring, 8 = 256x256 four-phase with the deep prefetch  (3 ring, 4 persistent, 7 four-wave, 10 register-double-buffered ring: `make EXPERIMENTS=1` builds only)
 
 
 @pytest.mark.parametrize("kernel", GEMM_KERNELS)
@@ -171,6 +171,29 @@ def test_encoder_fp16_operands_are_8x_closer(gpu_lib, b32_weights, golden_encode
     diff = np.abs(emb @ rows.T - golden_encoder["embeddings"] @ rows.T)
     assert diff.max() <= 3e-4
     print(f"fp16 operands: max L2 err {err.max():.2e}, max score diff {diff.max():.2e}")
+
+
+def test_encoder_hand_scheduled_gemms_are_bit_identical(gpu_lib, b32_weights, monkeypatch):
+    """$VQ_AMD_GEMM24 = 31 sends every full-batch GEMM of the tower (patch embedding, qkv, out_proj, fc1, fc2) through the
+    four-wave kernel whose K loop is one hand-scheduled asm text (csrc/gemm_asm256.h): same MFMA order per accumulator and the
+    same epilogue arithmetic, so 256 frames must encode to the SAME bits as the default kernels - with each of the tower's
+    epilogues (LayerNorm-consuming 16-bit stores, residual + LayerNorm partials, position embedding) reading its accumulators
+    out of the AGPR half pass by pass."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    frames = synth_frames(256, seed=24)
+    out = {}
+    for mask in ("0", "31"):
+        monkeypatch.setenv("VQ_AMD_GEMM24", mask)
+        for concurrent in (False, True):
+            enc = VitEncoder(VIT_B_32, b32_weights, max_batch=256, concurrent=concurrent)
+            out[mask, concurrent] = enc.encode(frames)
+            enc.close()
+    assert np.array_equal(out["31", True], out["0", True])
+    assert np.array_equal(out["31", False], out["31", True])
+    assert np.abs(out["31", False] - out["0", False]).max() <= 2e-3      # a lone handle's default uses 160-row tiles: other padding rows
+    ref = clip_vit_oracle.encode_frames(frames[:8], b32_weights, batch_size=8)
+    assert np.sum(out["31", True][:8] * ref, axis=1).min() >= 1.0 - COS_TOL
 
 
 def test_shared_weight_handles(gpu_lib, b32_weights):

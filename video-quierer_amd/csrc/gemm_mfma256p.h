@@ -30,6 +30,7 @@
 #include "gemm_mfma128x256p.h"
 #endif
 #include "gemm_mfma256f.h"
+#include "gemm_asm256.h"
 
 namespace vq {
 
@@ -312,6 +313,11 @@ static inline bool gemm_use_tail_split() {     // $VQ_AMD_GEMM_TAIL=0 keeps one 
 template <bool IS_F16, class Epi>
 static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                             int M, int N, int K, const Epi& epi, int force = 0) {
+    // 24: the hand-scheduled four-wave 256x256 mainloop (gemm_asm256.h) on every shape that tiles
+    if (force == 24) {
+        if (M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0) return launch_gemm_tn256a<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
+        force = 6;
+    }
     // 20 / 21: persistent out-of-phase 128x256 tiles, two workgroups per CU (gemm_mfma128x256p.h), on every shape that tiles
     // (20: the second workgroup of a CU starts half a tile late; 21: no lag — the in-step control of the A/B)
 #ifdef VQ_GEMM_EXPERIMENTS

@@ -162,7 +162,7 @@ int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long*
 
 
 // One GEMM kernel with one of the tower's epilogues, timed in isolation on fp16 operands (random, |v| <= 1).
-//   kernel: 8 = 256x256 deep prefetch (gemm_tn256d), 20 = persistent out-of-phase 128x256 (gemm_tn128x256p), 12 = the
+//   kernel: 8 = 256x256 deep prefetch (gemm_tn256d), 24 = the hand-scheduled four-wave 256x256 (gemm_tn256a), 20 = persistent out-of-phase 128x256 (gemm_tn128x256p), 12 = the
 //           non-persistent 128x256 two-per-CU experiment (EXPERIMENTS builds)
 //   epi:    0 = fp32 store, 1 = bias + residual + 16-bit copy + LayerNorm row partials (out_proj / fc2), 2 = LayerNorm-consuming
 //           quick-GELU 16-bit store (fc1), 3 = the same without GELU (qkv)
@@ -176,7 +176,7 @@ int vq_debug_gemm_bench(int M, int N, int K, int kernel, int mode, int dephase_c
     VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2));
     VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4)); VQ_HIP(hipMalloc(&dH, (size_t)M * N * 2));
     VQ_HIP(hipMalloc(&dV, (size_t)N * 4 * 2)); VQ_HIP(hipMalloc(&dP, (size_t)LN_MAX_GRANULES * M * 8));
-    VQ_HIP(hipMalloc(&dS, (size_t)4096 * 4 * 8));
+    VQ_HIP(hipMalloc(&dS, (size_t)4096 * 4 * 8));        // (kernel 24's clock pairs: 8192 workgroups x 2)
     VQ_HIP(hipMemset(dC, 0, (size_t)M * N * 4)); VQ_HIP(hipMemset(dV, 0, (size_t)N * 8)); VQ_HIP(hipMemset(dP, 0, (size_t)LN_MAX_GRANULES * M * 8));
     VQ_HIP(hipMemset(dS, 0, (size_t)4096 * 4 * 8));
     {
@@ -203,6 +203,14 @@ int vq_debug_gemm_bench(int M, int N, int K, int kernel, int mode, int dephase_c
             if (kernel == 12) return launch_gemm_tn128x256<true>(nullptr, dA, K, dW, K, M, N, K, e);
 #endif
             if (kernel == 8) return launch_gemm_tn256d<true>(nullptr, dA, K, dW, K, M, N, K, e);
+            if (kernel == 24) {              // mode: 0 = the product schedule, 1-5 = timing ablations (no DMA / no DMA, no reads / all waves in the same DMA slots (valid results) / no MFMAs / no MFMAs, no reads)
+                if (mode == 1) return launch_gemm_tn256a<true, decltype(e), 1>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 2) return launch_gemm_tn256a<true, decltype(e), 2>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 3) return launch_gemm_tn256a<true, decltype(e), 3>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 4) return launch_gemm_tn256a<true, decltype(e), 4>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 5) return launch_gemm_tn256a<true, decltype(e), 5>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                return launch_gemm_tn256a<true>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+            }
             return fail(VQ_ERR_INVALID, "vq_debug_gemm_bench: kernel %d is not available in this build", kernel);
         });
     };
@@ -217,6 +225,16 @@ int vq_debug_gemm_bench(int M, int N, int K, int kernel, int mode, int dephase_c
     float ms = 0.f;
     VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_avg = ms / reps;
+    if (rc == 0 && census && kernel == 24) {       // census[0] = median clock inside the K loop (MHz), census[1] = median K-loop cycles per workgroup
+        const int wgs = (M / 256) * (N / 256) > 8192 ? 8192 : (M / 256) * (N / 256);
+        std::vector<unsigned long long> st((size_t)wgs * 2);
+        VQ_HIP(hipMemcpy(st.data(), dS, st.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> mhz; std::vector<unsigned long long> cyc;
+        for (int i = 0; i < wgs; ++i) if (st[2 * i + 1]) { mhz.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 100.0); cyc.push_back(st[2 * i]); }
+        std::sort(mhz.begin(), mhz.end()); std::sort(cyc.begin(), cyc.end());
+        census[0] = mhz.empty() ? 0 : (unsigned long long)mhz[mhz.size() / 2];
+        census[1] = cyc.empty() ? 0 : cyc[cyc.size() / 2];
+    } else
     if (rc == 0 && census) {
         const int g = grid > 0 ? grid : 512;
         VQ_HIP(hipMemcpy(census, dS, (size_t)(g > 4096 ? 4096 : g) * 4 * 8, hipMemcpyDeviceToHost));

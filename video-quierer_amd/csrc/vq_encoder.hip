@@ -88,6 +88,9 @@ struct vq_encoder {
     float patch_unscale = 1.0f;   // 2^-s: undoes the power-of-two scale on fp16 patch weights (EpiPatchEmbedF32)
     int f16_mask = 0;        // per-GEMM-group operand type, DT_* bits (set = fp16, clear = bf16): create flags / $VQ_AMD_DTYPE
     bool h_is_f16 = false;   // type of what `h` holds right now (debug_read)
+    int gemm24_mask = 0;     // $VQ_AMD_GEMM24: which full-batch GEMMs run the hand-scheduled four-wave kernel (gemm_asm256.h): 1 qkv, 2 out_proj, 4 fc1, 8 fc2, 16 patch
+                             // embedding.  Default none: 16 % fewer cycles per K-tile, and the chip answers with a 14 % lower clock - frames/s equal within 1 %
+                             // with three batches in flight, +1.3 % for fc2 on a lone handle, -1 % on ViT-L/14 (DESIGN.md §4 "Round 3" (5))
     int gemm_force = 0;      // $VQ_AMD_GEMM: 0 auto, 1 = 128x128 kernel only, 2 = 256x256 wherever it tiles, 6 = auto without 160-row tiles
     // profiling
     bool profiling = false;
@@ -227,10 +230,17 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     };
     const int rows_gemm = pad_rows(rows);
     // per-GEMM row count: 160-row tiles where they occupy more CUs than 256-row tiles (gemm_mfma160.h)
-    auto gemm_rows = [&](int N, int K) {
+    // the hand-scheduled four-wave kernel (gemm_asm256.h) for the GEMMs $VQ_AMD_GEMM24 names, where 256-row tiles fill half the chip
+    auto use24 = [&](int bit, int M, int N, int K) {
+        return (e->gemm24_mask & bit) && (e->gemm_force == 0 || e->gemm_force == 6) && M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0 &&
+               (int64_t)(M / G2_BM) * (N / G2_BN) >= 128;
+    };
+    auto gemm_rows = [&](int N, int K, int bit = 0) {
+        if (use24(bit, rows_gemm, N, K)) return rows_gemm;
         const int r160 = (int)round_up(rows, G5_BM);
         return (e->gemm_force == 0 && gemm_use160() && r160 <= e->rows_pad && prefer_tn160(r160, N, K)) ? r160 : rows_gemm;
     };
+    auto gf = [&](int bit, int M, int N, int K) { return use24(bit, M, N, K) ? 24 : e->gemm_force; };
     const int prows = n * e->patches;
     const int prows_gemm = pad_rows(prows);
     const LnPartials part{e->ps, e->rows_pad};
@@ -268,7 +278,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         Prof p(e, C_GEMM_PATCH);
         VQ_TRY(by_f16(fP, [&](auto F) {
             return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, e->patch_k, e->w_patch, e->patch_k, prows_gemm, H, e->patch_k,
-                                               EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows, e->patch_unscale}, e->gemm_force);
+                                               EpiPatchEmbedF32{e->x, H, e->b_patch, e->pos, e->patches, T, prows, e->patch_unscale}, gf(16, prows_gemm, H, e->patch_k));
         }));
     }
     {   // CLS row, pre_layrnorm (in place); xh + row partials for the LN1 folded into layer 0's qkv GEMM
@@ -289,7 +299,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                 return by_f16(fA, [&](auto FO) {
                     return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_qkv, H, rows_gemm, 3 * H, H,
                                                        EpiLnH16<VQ_F16(FO), false>{e->qkv, 3 * H, L.c2_qkv, L.c1_qkv, part, granules, inv_h, c.ln_eps},
-                                                       e->gemm_force);
+                                                       gf(1, rows_gemm, 3 * H, H));
                 });
             }));
         }
@@ -371,8 +381,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
             Prof p(e, C_GEMM_OUT);
             VQ_TRY(by_f16(fA, [&](auto F) {
                 return by_f16(f1, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H), H, H,
-                                                       EpiBiasResidualLnF32<0, VQ_F16(FO)>{e->x, H, L.b_out, e->h, part}, e->gemm_force);
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H, 2), H, H,
+                                                       EpiBiasResidualLnF32<0, VQ_F16(FO)>{e->x, H, L.b_out, e->h, part}, gf(2, rows_gemm, H, H));
                 });
             }));
             e->h_is_f16 = f1;
@@ -383,7 +393,7 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                 return by_f16(f2, [&](auto FO) {
                     return launch_gemm_auto<VQ_F16(F)>(st, e->h, H, L.w_fc1, H, rows_gemm, c.mlp, H,
                                                        EpiLnH16<VQ_F16(FO), true>{e->mlp, c.mlp, L.c2_fc1, L.c1_fc1, part, granules, inv_h, c.ln_eps},
-                                                       e->gemm_force);
+                                                       gf(4, rows_gemm, c.mlp, H));
                 });
             }));
         }
@@ -391,8 +401,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
             Prof p(e, C_GEMM_FC2);
             VQ_TRY(by_f16(f2, [&](auto F) {
                 return by_f16(fQ, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp), H, c.mlp,
-                                                       EpiBiasResidualLnF32<1, VQ_F16(FO)>{e->x, H, L.b_fc2, e->h, part}, e->gemm_force);
+                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp, 8), H, c.mlp,
+                                                       EpiBiasResidualLnF32<1, VQ_F16(FO)>{e->x, H, L.b_fc2, e->h, part}, gf(8, rows_gemm, H, c.mlp));
                 });
             }));
             e->h_is_f16 = fQ;
@@ -464,6 +474,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     vq_encoder* e = new vq_encoder();
     if (flags & VQ_ENC_CONCURRENT) e->gemm_force = 6;        // auto, without the 160-row tiles
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
     if (const char* at = getenv("VQ_AMD_ATTN")) e->attn_simple = !strcmp(at, "simple");
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->f16_mask = dtype_mask_from(flags);
@@ -573,6 +584,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->patch_unscale = parent->patch_unscale;
     e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
     e->attn_simple = parent->attn_simple; e->prune_last = parent->prune_last;
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = round_up((int64_t)max_batch * e->patches, 256);
@@ -635,6 +647,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
     e->f16_mask = dtype_mask_from(flags);
     auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
 
