@@ -166,10 +166,26 @@ class HNSWIndex:
             # row-wise `v / np.linalg.norm(v)` exactly as the reference computes it (:157)
             unit = self._unit_rows(vs)
             unit = np.ascontiguousarray(unit, dtype=np.float32)
+            ids_n = node_ids[:n]
+            if self._row_of.keys().isdisjoint(ids_n) and len(set(ids_n)) == n:
+                # the ingest case (video_search_system.py:168-176: every frame id is new): no per-id walk
+                _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(unit), n, 0))
+                base = len(self._ids)
+                self._row_of.update(zip(ids_n, range(base, base + n)))
+                if self._identity:
+                    arr = np.asarray(ids_n)
+                    if not (arr.ndim == 1 and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(base, base + n))):
+                        self._identity = False
+                self._ids.extend(ids_n)
+                self.element_count += n                                   # reference counts every add (:229)
+                if self.entry_point is None:
+                    self.entry_point = self._ids[0]
+                self.build_time += time.time() - t0
+                return
             fresh_rows, fresh_ids = [], []
             upd_rows, upd_src = [], []                                   # re-added ids: (stored row, batch position), in call order
             seen_now: Dict[Hashable, int] = {}
-            for j, nid in enumerate(node_ids[:n]):
+            for j, nid in enumerate(ids_n):
                 if nid in self._row_of:
                     upd_rows.append(self._row_of[nid]); upd_src.append(j)
                 elif nid in seen_now:                                    # later duplicate wins (dict semantics)
