@@ -815,8 +815,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  int32_t* __restrict__ flags, float eps_rows,
                                  int32_t* __restrict__ slots1 /* with counters1: a ONE-query launch writes the flagged list and */,
                                  int32_t* __restrict__ counters1 /* the outcome counters itself (collect_flags_kernel's job) */) {
-    __shared__ float sel_v[4 * RV_C];
-    __shared__ int sel_s[4 * RV_C];
+    __shared__ __attribute__((aligned(8))) int2 sel[4 * RV_C];      // {key bits, source}: one 8-byte LDS access per entry
     __shared__ float wave_floor[4];
     __shared__ float red[256];
     __shared__ float cand_key[RV_C];
@@ -840,22 +839,40 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     //         32 keys are >= T and the overall best RV_C are among them; pass B collects the keys >= T (a few dozen) and the
     //         largest key below T.  (Stamps: the insertion lists cost ~30 instructions per key whenever ANY lane of the wave
     //         inserted — 23k cycles; ranking the 256 maxima against each other another ~10k.) ----
-    constexpr int PF = 16;
+    constexpr int PF = 16, KEEP_ROUNDS = 2;
     const uint2 NONE = uint2{0xFF800000u, 0xFF800000u};      // a missing stream reads as -inf
     const uint32_t* qkeys = keys + (size_t)q * streams * 2;    // layout 3: query-major
     // thread -> first stream: by thread id (a wave reads 512 contiguous bytes); on a small index interleaved over the waves,
     // so that every wave owns at least 8 streams as soon as the keys no longer all fit the collected list
     const int p0 = streams < 512 ? 4 * lane + wave : tid;
-    float mx = NEG;
-    for (int64_t s = p0; s < streams; s += PF * 256) {
-        uint2 two[PF];
+    // up to KEEP_ROUNDS x PF x 256 streams (1M rows) the keys of pass A STAY in registers for pass B: the second read and its
+    // two round trips (stamps: pass B was 26k of the kernel's 73k cycles) are gone
+    const bool keep = streams <= (int64_t)KEEP_ROUNDS * PF * 256;      // workgroup-uniform
+    uint2 kept[KEEP_ROUNDS][PF];
+    auto load_round = [&](int64_t s, uint2 (&two)[PF]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) { const int64_t su = s + u * 256; two[u] = su < streams ? *(const uint2*)(qkeys + su * 2) : NONE; }
+    };
+    float mx = NEG;
+    if (keep) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) mx = fmaxf(mx, __builtin_bit_cast(float, two[u].x));      // a stream's 2nd key is never above its 1st
+        for (int r = 0; r < KEEP_ROUNDS; ++r) {
+            load_round(p0 + (int64_t)r * PF * 256, kept[r]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) mx = fmaxf(mx, __builtin_bit_cast(float, kept[r][u].x));      // a stream's 2nd key is never above its 1st
+        }
+    } else {
+        for (int64_t s = p0; s < streams; s += PF * 256) {
+            uint2 two[PF];
+            load_round(s, two);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) mx = fmaxf(mx, __builtin_bit_cast(float, two[u].x));
+        }
     }
     VQ_RS_STAMP(1);
-    {   // the wave's 8th largest maximum: take the wave maximum eight times, retiring one holder each time
+    {   // the wave's 8th largest maximum: take the wave maximum eight times, retiring one holder each time.  (Touching the retiring
+        // lanes' rows of the fp32 master here, by LDS-DMA into a scratch word, so that step 3's 16 random 2-KiB rows would find
+        // their translations ready, did not move step 3's 19k cycles: removed again.)
         float cur = mx, t8 = NEG;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -882,12 +899,10 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     {
         float below = NEG;                                     // best key NOT collected
         const float thr_eff = fmaxf(thr, -3.4e38f);            // thr = -inf on a tiny index: every real key (they are finite), never a missing one
-        for (int64_t s = p0; s < streams; s += PF * 256) {
-            uint2 two[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { const int64_t su = s + u * 256; two[u] = su < streams ? *(const uint2*)(qkeys + su * 2) : NONE; }
-            // which of the round's 32 keys this lane collects, as a bit mask; then ONE LDS atomic per wave and round (a ballot, an
-            // atomic and a shuffle per key slot were 28k cycles of this kernel: ~50 keys pass, spread over most slots)
+        // one round of 32 keys per lane: which of them the lane collects as a bit mask, the lanes' counts scanned over the wave
+        // (six shuffles), ONE LDS atomic per wave and round for the wave's run in the list, then the predicated stores.  (A ballot, an
+        // atomic and a shuffle per key slot were 28k cycles of this kernel; a scalar walk over the collecting lanes ~1k per round.)
+        auto collect_round = [&](int64_t s, const uint2 (&two)[PF]) __attribute__((always_inline)) {
             unsigned km = 0;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -896,31 +911,36 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                 km |= (k0 ? 1u : 0u) << (2 * u) | (k1 ? 1u : 0u) << (2 * u + 1);
                 below = fmaxf(below, fmaxf(k0 ? NEG : v0, k1 ? NEG : v1));
             }
-            unsigned long long holders = __ballot(km != 0);
-            if (holders) {                                      // wave-uniform
-                int total = 0, mine = 0;
-                while (holders) {                               // scalar walk over the lanes that collect something: their offsets
-                    const int l = __builtin_ctzll(holders);
-                    holders &= holders - 1;
-                    const int c = __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)km, l));
-                    if (lane == l) mine = total;
-                    total += c;
-                }
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&surv_n, total);
-                int pos = __builtin_amdgcn_readfirstlane(base) + mine;
-                if (km) {
+            if (__ballot(km != 0) == 0) return;                // wave-uniform
+            const int mine = __builtin_popcount(km);
+            int incl = mine;
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) {
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&surv_n, total);
+            int pos = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+            if (km) {
 #pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            if (km >> (2 * u + w) & 1u) {
-                                if (pos < 4 * RV_C) { sel_v[pos] = __builtin_bit_cast(float, w ? two[u].y : two[u].x); sel_s[pos] = (int)((s + u * 256) * 2) + w; }
-                                ++pos;
-                            }
+                for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        if (km >> (2 * u + w) & 1u) {
+                            if (pos < 4 * RV_C) sel[pos] = int2{(int)(w ? two[u].y : two[u].x), (int)((s + u * 256) * 2) + w};
+                            ++pos;
                         }
                     }
                 }
+            }
+        };
+        if (keep) {
+#pragma unroll
+            for (int r = 0; r < KEEP_ROUNDS; ++r) collect_round(p0 + (int64_t)r * PF * 256, kept[r]);
+        } else {
+            for (int64_t s = p0; s < streams; s += PF * 256) {
+                uint2 two[PF];
+                load_round(s, two);
+                collect_round(s, two);
             }
         }
         below = wave64_max(below);
@@ -930,11 +950,24 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     {
         const int ns = min(surv_n, 4 * RV_C);                                // more keys than the list holds reach the threshold: flagged in step 4
         if (tid < ns) {
-            const float vi = sel_v[tid]; const int si = sel_s[tid];
+            const float vi = __builtin_bit_cast(float, sel[tid].x); const int si = sel[tid].y;
             int rank = 0;
-            for (int j2 = 0; j2 < ns; ++j2) {
-                const float vj = sel_v[j2];
-                rank += (vj > vi) || (vj == vi && sel_s[j2] < si);            // sources are distinct: ranks are a permutation
+            // the list is read as a broadcast, eight entries per trip in flight (one dependent LDS round trip per entry was 6-13k cycles)
+            int j2 = 0;
+            for (; j2 + 8 <= ns; j2 += 8) {
+                int2 e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = sel[j2 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float vj = __builtin_bit_cast(float, e[u].x);
+                    rank += (vj > vi) || (vj == vi && e[u].y < si);            // sources are distinct: ranks are a permutation
+                }
+            }
+            for (; j2 < ns; ++j2) {
+                const int2 e = sel[j2];
+                const float vj = __builtin_bit_cast(float, e.x);
+                rank += (vj > vi) || (vj == vi && e.y < si);
             }
             if (rank < RV_C) { cand_key[rank] = vi; cand_src[rank] = si; }
             if (rank == RV_C) bound_rest_s = vi;
