@@ -740,8 +740,14 @@ void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restr
 // row-major for the transposed reads) and shared by its 4 waves, and the next key step's loads are in
 // flight while the current one is consumed.  (The per-wave version re-read K and V from global memory
 // once per query tile and ran at ~280 TFLOP/s on ViT-L/14@336, 32 % of that model's step.)
-template <bool F16, bool CAUSAL>
-__global__ __launch_bounds__(256, 2)
+// NQ = 16-row query blocks per wave: 4 (64 rows, the form above) or 2.  With 32 rows per wave the kernel needs half the
+// accumulator, query and score registers (three waves per SIMD instead of two; compiled for four it spills 9 dwords and is no
+// faster) and 577 tokens pad to 19 x 32 = 608 rows instead of 640; the K and V tiles are then shared by 128 query rows per
+// workgroup instead of 256 (twice the LDS-DMA traffic, which is small beside the softmax).  ViT-L/14@336, 32 frames: attention
+// 3.33 -> 2.83 ms per step (0.126 -> 0.148 of the MFMA peak on the 577^2 count), 2,292 -> 2,338 frames/s.  NQ = 2 is
+// instantiated for the non-causal (image) tower only; $VQ_AMD_ATTN=q64 selects the 64-row form for A/B.
+template <bool F16, bool CAUSAL, int NQ = 4>
+__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2)
 void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                 int tokens, int hidden, int heads, int q_tiles, int q_groups) {
     __shared__ __attribute__((aligned(16))) uint16_t klds[2][64 * 64];
@@ -760,7 +766,9 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     const int ld = 3 * hidden;
     const uint16_t* base = qkv + (size_t)img * tokens * ld + head * 64;
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = qt * 64;
+    static_assert(NQ == 4 || (NQ == 2 && !CAUSAL), "32-row query tiles: image tower only (the causal bounds assume 64-row tiles)");
+    constexpr int QROWS = 16 * NQ;
+    const int q0 = qt * QROWS;
 
     // Rows past `tokens` are never written by the tile loads below; zero both buffers once so that whatever a
     // masked key position holds is finite (its probability is 0, and 0 * finite = 0 in the P.V product).
@@ -769,9 +777,9 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
         ((uint4*)&vlds[0][0])[i] = uint4{0u, 0u, 0u, 0u};
     }
 
-    frag qf[4][2];
+    frag qf[NQ][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NQ; ++t) {
         const int row = q0 + t * 16 + r16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -780,15 +788,17 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
             qf[t][ks] = __builtin_bit_cast(frag, qv);
         }
     }
-    f32x4 o[4][4];
+    f32x4 o[4][NQ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NQ; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float NEGBIG = -3.0e38f;
     const float L2E = 1.44269504088896341f;
     // running maximum in the log2 domain (score * log2 e): p = exp2(score * log2e - m2) is one fma + one v_exp
-    float m_run[4] = {NEGBIG, NEGBIG, NEGBIG, NEGBIG}, l_run[4] = {0.f, 0.f, 0.f, 0.f};
+    float m_run[NQ], l_run[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { m_run[j] = NEGBIG; l_run[j] = 0.f; }
 
     const int all_k_tiles = (tokens + 63) / 64;
     const int last_q_tile = min(q_tiles - 1, qg * 4 + 3);
@@ -840,7 +850,7 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
             // the 64 query rows of the wave are independent: two passes of 32 rows keep the live score /
             // probability registers at half (the whole kernel then fits 2 waves per SIMD)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < NQ / 2; ++hh) {
                 f32x4 sc[4][2];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -923,7 +933,7 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     }
     if (!live) return;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NQ; ++nt) {
         const int qrow = q0 + nt * 16 + r16;
         const float inv = 1.0f / l_run[nt];
         if (qrow < tokens) {

@@ -84,6 +84,7 @@ struct vq_encoder {
     bool is_text = false;       // CLIP text tower (vq_text_encoder_*): token embedding, causal attention, EOS pooling
     float* tok_emb = nullptr; int* d_ids = nullptr; int* d_rowidx = nullptr; int vocab = 0, eos_id = 0;
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
+    bool attn_q64 = false;      // $VQ_AMD_ATTN=q64: 64 query rows per wave (the round-2 form) instead of 32 (A/B switch)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     float patch_unscale = 1.0f;   // 2^-s: undoes the power-of-two scale on fp16 patch weights (EpiPatchEmbedF32)
     int f16_mask = 0;        // per-GEMM-group operand type, DT_* bits (set = fp16, clear = bf16): create flags / $VQ_AMD_DTYPE
@@ -320,6 +321,10 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                         const int units = n * c.heads * q_tiles;
                         hipLaunchKernelGGL((attention_stream_kernel<F16, false>), dim3(cdiv(units, 4)), dim3(256), 0, st, e->qkv,
                                            e->att, T, H, c.heads, q_tiles, units);
+                    } else if (!e->attn_q64) {                  // 32 query rows per wave, three waves per SIMD (encoder_kernels.h)
+                        const int q_tiles32 = cdiv(T, 32), q_groups32 = cdiv(q_tiles32, 4);
+                        hipLaunchKernelGGL((attention_stream_wg_kernel<F16, false, 2>), dim3(n * c.heads * q_groups32), dim3(256), 0, st,
+                                           e->qkv, e->att, T, H, c.heads, q_tiles32, q_groups32);
                     } else {
                         hipLaunchKernelGGL((attention_stream_wg_kernel<F16, false>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
                                            e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
@@ -475,7 +480,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     if (flags & VQ_ENC_CONCURRENT) e->gemm_force = 6;        // auto, without the 160-row tiles
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
-    if (const char* at = getenv("VQ_AMD_ATTN")) e->attn_simple = !strcmp(at, "simple");
+    if (const char* at = getenv("VQ_AMD_ATTN")) { e->attn_simple = !strcmp(at, "simple"); e->attn_q64 = !strcmp(at, "q64"); }
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->f16_mask = dtype_mask_from(flags);
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
@@ -585,7 +590,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
-    e->attn_simple = parent->attn_simple; e->prune_last = parent->prune_last;
+    e->attn_simple = parent->attn_simple; e->attn_q64 = parent->attn_q64; e->prune_last = parent->prune_last;
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = round_up((int64_t)max_batch * e->patches, 256);
     e->weights_owner = parent->weights_owner ? parent->weights_owner : parent->arena_owner;   // a clone of a clone still pins the original weights
