@@ -511,8 +511,7 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 if (key >= tokens) s[mt][nt][r] = -3.0e38f;
                 mx = fmaxf(mx, s[mt][nt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = rows4_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -522,8 +521,7 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 s[mt][nt][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = rows4_sum(sum);
         inv_sum[nt] = 1.0f / sum;
     }
 
@@ -672,8 +670,7 @@ void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restr
                     if (key >= tokens || (CAUSAL && key > query)) sc[mt][nt][r] = NEGBIG;
                     mx = fmaxf(mx, sc[mt][nt][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = rows4_max(mx);
             const float m_new = fmaxf(m_run[nt], mx);
             alpha[nt] = __expf(m_run[nt] - m_new);          // 0 on the first tile (m_run = -3e38)
             float sum = 0.f;
@@ -686,8 +683,7 @@ void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restr
                     sc[mt][nt][r] = p;
                     sum += p;
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = rows4_sum(sum);
             l_run[nt] = l_run[nt] * alpha[nt] + sum;
             m_run[nt] = m_new;
         }
@@ -833,7 +829,11 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     fetch(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < wg_k_tiles; ++kt) {
+    // One key step.  EDGE = the masking of keys past the sequence end (and, causal, past the query) is compiled in: as a run-time
+    // flag it was if-converted into a compare and a select per score on EVERY tile.  The image tower masks only in its LAST key
+    // step, which is peeled off the loop below; the causal (text) tower, two key steps long, masks in every step.
+    auto key_step = [&](int kt, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const int buf = kt & 1;
         if (kt + 1 < wg_k_tiles) fetch(kt + 1, buf ^ 1);    // the other buffer was last read in step kt-1 (barrier below it)
         if (kt < my_k_tiles) {
@@ -846,7 +846,6 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     kf[t][ks] = *(const frag*)(kt_l + (t * 16 + r16) * 64 + (((ks * 4 + g) ^ kfx) * 8));
-            const bool edge = (k0 + 64 > tokens) || (CAUSAL && kt == qt);      // only these tiles need masking
             // the 64 query rows of the wave are independent: two passes of 32 rows keep the live score /
             // probability registers at half (the whole kernel then fits 2 waves per SIMD)
 #pragma unroll
@@ -871,14 +870,13 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if (edge) {
+                            if constexpr (EDGE) {
                                 const int key = k0 + mt * 16 + g * 4 + r;
                                 if (key >= tokens || (CAUSAL && key > query)) sc[mt][j][r] = NEGBIG;
                             }
                             mx = fmaxf(mx, sc[mt][j][r]);
                         }
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = rows4_max(mx);
                     const float m_new = fmaxf(m_run[nt], mx * L2E);
                     alpha[j] = __builtin_amdgcn_exp2f(m_run[nt] - m_new);
                     float sum = 0.f;
@@ -887,12 +885,11 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mt][j][r], L2E, -m_new));
-                            if (edge && sc[mt][j][r] <= NEGBIG) p = 0.f;
+                            if (EDGE && sc[mt][j][r] <= NEGBIG) p = 0.f;
                             sc[mt][j][r] = p;
                             sum += p;
                         }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
+                    sum = rows4_sum(sum);
                     l_run[nt] = l_run[nt] * alpha[j] + sum;
                     m_run[nt] = m_new;
                 }
@@ -930,6 +927,12 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed
         __syncthreads();
+    };
+    if constexpr (CAUSAL) {
+        for (int kt = 0; kt < wg_k_tiles; ++kt) key_step(kt, std::true_type{});
+    } else {
+        for (int kt = 0; kt + 1 < wg_k_tiles; ++kt) key_step(kt, std::false_type{});
+        key_step(wg_k_tiles - 1, std::true_type{});
     }
     if (!live) return;
 #pragma unroll

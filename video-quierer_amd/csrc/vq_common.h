@@ -99,4 +99,32 @@ __device__ __forceinline__ float wave64_max(float x) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Reductions ACROSS the four 16-lane rows of a wave (lane ^ 16, then lane ^ 32), the result in every lane: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange odd and even rows (upper and lower halves) of two registers in one vector
+// instruction; with both operands the same value, the two results hold {self, partner} in some order in every lane, so a
+// commutative combine of them is the xor-butterfly step — same operand pairs as __shfl_xor(x, 16) / (x, 32), bit-identical,
+// without the two ds_bpermute_b32 round trips through the LDS crossbar (~100+ cycles each on the softmax's critical path).
+// Written as inline asm on two in/out registers: through __builtin_amdgcn_permlane{16,32}_swap this compiler (ROCm 7.2) folds
+// op(result[0], result[1]) to op(result[0], result[0]) whenever both inputs hold the same value (scripts/ubench/rows4_check.hip
+// showed max = own value and sum = 4 x own).  The s_nop pads the VALU-write -> permlane-read hazard the asm hides from the
+// compiler's hazard recogniser.
+__device__ __forceinline__ void rows_swap16(float x, float& a, float& b) {
+    a = x; b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void rows_swap32(float x, float& a, float& b) {
+    a = x; b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows4_max(float x) {
+    float a, b;
+    rows_swap16(x, a, b); x = fmaxf(a, b);
+    rows_swap32(x, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+    float a, b;
+    rows_swap16(x, a, b); x = a + b;
+    rows_swap32(x, a, b); return a + b;
+}
+
 }  // namespace vq
