@@ -784,6 +784,10 @@ constexpr int RVX_QPW = 4, RVX_KEEP = 12, RVX_C = 128;
 static const auto rescore_verify_kernel = rescore_verify_kernel_t<RV_QPW, RV_KEEP, RV_C>;
 static const auto rescore_verify_large_kernel = rescore_verify_kernel_t<RVL_QPW, RVL_KEEP, RVL_C>;
 static const auto rescore_verify_xlarge_kernel = rescore_verify_kernel_t<RVX_QPW, RVX_KEEP, RVX_C>;
+// small batches (the streaming scan's query-major keys) with k > RV_K_SMALL: ONE query per workgroup, so that 256 threads instead
+// of 64 walk the query's 2 x streams keys (one query, k = 40, 1M rows: 0.36 ms with the four-queries-per-workgroup form above)
+static const auto rescore_verify_large1_kernel = rescore_verify_kernel_t<1, RVL_KEEP, RVL_C>;
+static const auto rescore_verify_xlarge1_kernel = rescore_verify_kernel_t<1, RVX_KEEP, RVX_C>;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small batches (nq <= SCAN3_MAX_Q, keys in layout 3): ONE workgroup per query instead of 16 queries per workgroup.

@@ -181,6 +181,11 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
 }
 
 // fp16 MFMA scan + exact re-score with proof; unproven queries go through search_exact.
+static bool large_qpw4() {          // $VQ_AMD_RESCORE_QPW4=1: the four-queries-per-workgroup kernel for small batches with k > 20 too (A/B switch)
+    static const bool v = getenv("VQ_AMD_RESCORE_QPW4") && atoi(getenv("VQ_AMD_RESCORE_QPW4")) == 1;
+    return v;
+}
+
 int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
     const int64_t n = x->size;
     // small batches (the reference's one-query-at-a-time search, video_search_system.py:297) take the HBM-bound
@@ -294,7 +299,11 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         {
             Prof p(x, I_RESCORE);
             const bool large = k > RV_K_SMALL;                  // k in (20, 64]: the wide candidate pool, whatever scan produced the keys
-            if (large)
+            if (large && ver == 3 && !large_qpw4())
+                hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge1_kernel : rescore_verify_large1_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_keys, streams,
+                                   q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
+                                   d_dist_out + q0 * k, x->d_flags + q0, 3, scan_eps_unit(x->dim) * x->row_norm_max);
+            else if (large)
                 hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge_kernel : rescore_verify_large_kernel, dim3(cdiv(cur, RVL_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                    q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
                                    d_dist_out + q0 * k, x->d_flags + q0, ver == 3 ? 3 : deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
