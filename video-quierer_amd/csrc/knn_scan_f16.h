@@ -1101,7 +1101,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
             const int which = i / SCAN_STREAM_ROWS, local = i - which * SCAN_STREAM_ROWS;
             const int64_t r = scan3_row_of(resc_stream[which], local);
             int row = -1; float d = __builtin_inff();
-            if (r < n_valid) { row = (int)r; d = 1.0f - exact_dot_chain(rows + (size_t)r * dim, qv, dim); }
+            if (r < n_valid) { row = (int)r; d = 1.0f - ((dim & 31) == 0 ? exact_dot_chain_pf(rows + (size_t)r * dim, qv, dim) : exact_dot_chain(rows + (size_t)r * dim, qv, dim)); }   // _pf: eight 16-byte loads in flight per thread (a stream rescan was ~35 us of one-load-per-step round trips)
             cand_row[RV_C + i] = row; cand_dist[RV_C + i] = d;
         }
     }
