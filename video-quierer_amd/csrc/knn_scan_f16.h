@@ -524,7 +524,7 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
     // 488 dependent round trips per thread made this kernel 1.8 ms for 10k queries)
     // batches of eight 8-byte loads, the next batch in flight while the current one is offered (one batch at a time waited a
     // full memory round trip per batch: 194k cycles for 32 batches)
-    constexpr int PF = 8;
+    constexpr int PF = QPW >= 8 ? 12 : 8;      // [r03] 12 loads in flight per thread where a thread walks the most keys (61 -> 41 dependent batches at 1M rows)
     auto key_at = [&](int64_t st) __attribute__((always_inline)) {       // element index of stream st's key pair of query q
         return layout == 3 ? ((size_t)q * streams + st) * 2 : batch_key_index(st, q, streams);
     };
