@@ -292,9 +292,9 @@ static int launch_gemm_tn256_best(hipStream_t st, const uint16_t* A, int lda, co
                            : launch_gemm_tn256<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 }
 
-static inline int gemm_multi_min_wgs() {        // $VQ_AMD_GEMM_MULTI_MIN: fewest workgroups a three-tile launch may leave (default 192)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_MULTI_MIN"); v = e ? atoi(e) : 192; }
+static inline int gemm_multi_min_wgs() {        // $VQ_AMD_GEMM_MULTI_MIN: fewest workgroups a three-tile launch may leave.  Default 128 [r03]: with
+    static int v = -1;                           // three batches in flight qkv (450 tiles -> 150 workgroups) gains 0.6-0.9 % frames/s too (192 kept it on single tiles)
+    if (v < 0) { const char* e = getenv("VQ_AMD_GEMM_MULTI_MIN"); v = e ? atoi(e) : 128; }
     return v;
 }
 
@@ -354,9 +354,10 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
 #ifdef VQ_GEMM_EXPERIMENTS
             if (force == 9 && lda % 64 == 0 && ldw % 64 == 0) return launch_gemm_tn256e<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
 #endif
-            // Three tiles of a tile row per workgroup where that still leaves >= 192 workgroups (fc1 at batch 256): the second
-            // and third tile's first operands land under the previous epilogue (fc1 -3.5 % with one batch in flight, +0.5 % frames/s
-            // with three; qkv would drop to 150 workgroups and lose 29 %).  Concurrent handles only: a lone batch keeps the
+            // Three tiles of a tile row per workgroup where that still leaves >= 128 workgroups (fc1 and, since round 3, qkv at batch
+            // 256): the second and third tile's first operands land under the previous epilogue (fc1 -3.5 % with one batch in flight,
+            // +0.5 % frames/s with three; qkv drops to 150 workgroups: -29 % alone, +0.6-0.9 % frames/s with three batches in flight —
+            // the idle CUs belong to the other batches then).  Concurrent handles only: a lone batch keeps the
             // tail-split dispatch below.  $VQ_AMD_GEMM_MULTI=0 switches it off, VQ_AMD_GEMM=15 forces it everywhere.
             if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= gemm_multi_min_wgs()) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0)
                 return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
