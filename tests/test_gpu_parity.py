@@ -1019,6 +1019,26 @@ def test_encoder_small_patch14_geometry_vs_oracle(gpu_lib):
         assert err <= tol, (dt, err)
 
 
+def test_encoder_patch16_geometry_both_attention_forms(gpu_lib, monkeypatch):
+    """197 tokens (224 / 16, squared, + CLS) = three full 64-key steps and one of five keys, seven 32-row query tiles (the last
+    with five rows): the streaming attention's 32-rows-per-wave form (default; masking compiled into the peeled last key step,
+    permlane-swap reductions) and the 64-row form ($VQ_AMD_ATTN=q64) against the fp32 oracle, and against each other."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VitConfig, seeded_weights
+    cfg = VitConfig(image_size=224, patch_size=16, hidden=768, mlp=3072, layers=2, heads=12, proj_dim=512)
+    W = seeded_weights(cfg, 78)
+    frames = np.random.default_rng(10).integers(0, 255, (6, 224, 224, 3), dtype=np.uint8)
+    ref = clip_vit_oracle.encode_frames(frames, W, patch=16, heads=12, layers=2, batch_size=6)
+    out = {}
+    for form in ("q32", "q64"):
+        monkeypatch.setenv("VQ_AMD_ATTN", form)
+        enc = VitEncoder(cfg, W, max_batch=8, compute_dtype="fp16")
+        out[form] = enc.encode(frames)
+        enc.close()
+        assert np.linalg.norm(out[form] - ref, axis=1).max() <= 8e-4, form
+    assert np.abs(out["q32"] - out["q64"]).max() <= 2e-4        # same arithmetic per row; only the online softmax's tile walk is shared
+
+
 def test_encoder_vit_l14_336_matches_golden(gpu_lib):
     """BASELINE configs[4] model: ViT-L/14@336, fp16 operands as that config names (and bf16)."""
     from conftest import GOLDEN, FRAME_SEED
