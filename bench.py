@@ -91,15 +91,51 @@ def supervise(argv) -> int:
     a FRESH child with --exchange torch (new rendezvous port: the old store died with rank 0's child) and the result line
     records which path ran.  A hung or failed bring-up therefore costs its deadline, not the run."""
     import subprocess
+    t_sup = time.time()
     env = dict(os.environ, VQ_BENCH_CHILD="1")
     rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + argv, env=env)
     if rc != RELAUNCH_CODE:
         return rc
     sys.stderr.write(f"bench.py[rank {os.environ.get('RANK', '?')}]: native RCCL bring-up gave up; relaunching this rank with --exchange torch\n")
     env["VQ_BENCH_EXCHANGE_NOTE"] = "relaunched after the native RCCL bring-up failed or timed out"
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    # The new rendezvous port: rank 0's supervisor finds one that is free NOW (the launcher only vouched for the original one)
+    # and hands it to the other supervisors of this node through a file named after the original port (one job = one port).
+    old_port = int(os.environ.get("MASTER_PORT", "29500"))
+    note = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vq_bench_relaunch_{old_port}.port")
+    if os.environ.get("RANK", "0") == "0":
+        import socket
+        port = old_port + 1
+        for cand in list(range(old_port + 1, old_port + 17)) + [0]:
+            try:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", cand))
+                    port = sk.getsockname()[1]
+                break
+            except OSError:
+                continue
+        with open(note + ".tmp", "w") as f:
+            f.write(str(port))
+        os.replace(note + ".tmp", note)
+    else:
+        port, t_end = old_port + 1, time.time() + 60.0
+        while time.time() < t_end:
+            try:
+                if os.path.getmtime(note) < t_sup - 1.0:      # left behind by an earlier job that used the same port
+                    raise OSError("stale")
+                with open(note) as f:
+                    port = int(f.read().strip())
+                break
+            except (OSError, ValueError):
+                time.sleep(0.1)
+    env["MASTER_PORT"] = str(port)
     env["TORCHELASTIC_USE_AGENT_STORE"] = "False"          # nobody serves the new port yet: rank 0's child hosts the store itself
-    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--exchange", "torch"], env=env)
+    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--exchange", "torch"], env=env)
+    if os.environ.get("RANK", "0") == "0":
+        try:
+            os.remove(note)
+        except OSError:
+            pass
+    return rc
 
 
 def bring_up_native(dist, torch, dev, make_comm, deadline_s):
@@ -503,6 +539,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp16": "fp16 MFMA operands (every GEMM group), fp32 accumulate", "mixed": "fp16 MFMA operands (bf16 for the patch-embed GEMM), fp32 accumulate"}.get(args.dtype, args.dtype),
+        # BASELINE.json configs[1] says bf16: same operand width and MFMA rate as fp16, three mantissa bits fewer
+        "dtype_note": ("configs[1] names bf16; the default here is fp16 MFMA operands (same 16-bit width, same MFMA rate, fp32 accumulation) because plain bf16 "
+                       "misses north_star's parity bar on config 1 (max cosine-score error 1.03e-3 > 1e-3, recall@5 0.9969 vs the reference pipeline; fp16: 1.1e-4, "
+                       "recall 1.0 - DESIGN.md section 2).  bf16 is selectable (--dtype bf16) and measured 2.6 % FASTER in a same-box A/B (102.9k vs 100.3k frames/s, "
+                       "profiles/r03_bench.json vs DESIGN section 5), i.e. the fp16 figure is the conservative one"),
         "data": "synthetic",
         "config": {"workload": (f"configs[1]: batch-{BATCH} ViT-B/32 encode of synthetic 224x224 RGB uint8 frames, "
                                 if args.model == "b32" else
@@ -560,7 +601,9 @@ def main():
             ach = fl / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16 / 1e12,
                                "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_BF16, "traffic": traffic,
-                               "traffic_source": tsrc, "avg_launch_ms": avg_ms, "flops_per_launch": fl,
+                               # NOT a measurement of this run: PMC counters cannot be read from inside the bench process, the figure is
+                               # replayed from the committed rocprofv3 --pmc passes of the same code at the same geometry
+                               "traffic_replayed_from": tsrc, "avg_launch_ms": avg_ms, "flops_per_launch": fl,
                                # HIP events on the launch stream: mean bracket around one full-size launch, the empty-bracket
                                # time measured the same way, avg_launch_ms = the difference (what rocprofv3 calls the duration)
                                "avg_event_bracket_ms": prof[dom]["raw_ms"] / max(prof[dom]["launches"], 1),
@@ -574,6 +617,7 @@ def main():
                                         if gemm_flops(k, rows, cfg) and v["ms"] > 0 else {})}
                                  for k, v in prof.items()}
 
+    cpu_legs = []        # CPU baselines / checks, run after every GPU leg (the GPU work is then contiguous on the box's clock)
     # ---- secondary: queries/s, top-10 over a row-sharded 1M x 512 matrix (configs[2]) ----
     if not args.no_search:
         n_rows, nq, k = args.search_rows // world, args.search_queries, 10
@@ -669,51 +713,119 @@ def main():
                                                    # is 1.02 GB, each 256-query tile re-streams it from L2 / Infinity Cache
                                                    "traffic": scan_traffic}
             srch["last_search_stats"] = idx.last_search_stats()
-        # CPU baselines for the search leg (rank 0, N=1 only), over the SAME matrix: what a CPU user would run
-        # (numpy sgemm brute force, the reference's live path video_search_overhaul.py:54 np.dot + argsort), the exact
-        # C checker (fp64-chain dot, OpenMP), and the pure-Python HNSW restatement (what the reference's modular path runs)
-        if rank == 0 and not args.no_cpu_baseline:
-            from oracle import hnsw_oracle, knn_oracle
-            import random as _random
-            host_rows = idx._export()
-            scope = "all" if world == 1 else "rank 0's shard of"      # N > 1: the CPU leg scans one shard, the GPU number is the whole matrix
-            ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
-            os.environ["OMP_NUM_THREADS"] = str(ncores)
-            qs_host = q[:512].cpu().numpy()
+        # ---- the drop-in called the way video_search_system.py calls it (:297): ONE synchronous `index.search(query, k*2)` at a
+        # time, numpy vector in, list of dicts out — a call's latency, not the rate of back-to-back asynchronous launches above;
+        # first with integer ids = row numbers, then under the caller's STRING ids f"{video_id}_{i}" (:164-166), where the
+        # device orders ties by id rank (vq_index_set_id_ranks) and the host maps rows to names ----
+        if rank == 0:
+            def host_sync_latency(index, k_, reps=200):
+                qh = q[:reps].cpu().numpy()
+                index.search(qh[0], k_)
+                ts = []
+                for i in range(reps):
+                    t0 = time.perf_counter()
+                    r_ = index.search(qh[i], k_)
+                    ts.append(time.perf_counter() - t0)
+                assert len(r_) == k_
+                ts = np.sort(np.array(ts)) * 1e3
+                return {"p50_ms": float(ts[len(ts) // 2]), "p95_ms": float(ts[int(len(ts) * 0.95)]), "mean_ms": float(ts.mean()), "calls": reps, "k": k_}
             try:
-                from threadpoolctl import threadpool_limits
-                blas_ctx = threadpool_limits(limits=ncores)
-            except ImportError:
-                import contextlib
-                blas_ctx = contextlib.nullcontext()
-            with blas_ctx:
-                nb = 256
+                torch.cuda.synchronize(dev)
+                hs = {"call": "OptimizedHNSWIndex.search(np.float32[dim], k): host vector in, list of {'id','distance','score'} out, one call at a time "
+                              "(video_search_system.py:297 asks for k*2 = 20 at the API's default k = 10)",
+                      "int_ids": host_sync_latency(idx, 20), "int_ids_k10": host_sync_latency(idx, 10)}
+                sidx = OptimizedHNSWIndex(dimension=dimq, device=local)
+                g2s = torch.Generator(device=dev)
+                g2s.manual_seed(7 + rank)                              # the same rows as `idx`
+                per_video = max(1, n_rows // 4)
+                for c0 in range(0, n_rows, 250_000):
+                    c = min(250_000, n_rows - c0)
+                    block = torch.randn((c, dimq), dtype=torch.float32, device=dev, generator=g2s)
+                    torch.cuda.synchronize(dev)
+                    sidx.add_device(block.data_ptr(), c, [f"video{r // per_video}_{r % per_video}" for r in range(c0, c0 + c)], normalize=True)
+                    sidx.synchronize()
+                del block
                 t0 = time.perf_counter()
-                sims = host_rows @ qs_host[:nb].T                                   # [N, nb] fp32 sgemm
-                part = np.argpartition(-sims, k, axis=0)[:k]
-                top = np.take_along_axis(part, np.argsort(-np.take_along_axis(sims, part, 0), axis=0), 0)
-                ct = time.perf_counter() - t0
-            srch["cpu_baseline"] = {"value": nb / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
-                                    "sample": f"{nb} of the {nq} queries in one numpy fp32 sgemm over {scope} {n_rows} rows + "
-                                              f"argpartition top-{k} (brute force as video_search_overhaul.py:54 computes it), {ct:.2f}s",
-                                    "agrees_with_gpu_top1": float(np.mean(top[0] == ids[:nb, 0].cpu().numpy())) if world == 1 else None}
+                sidx.search(q[0].cpu().numpy(), 20)                     # the first search ranks the ids and uploads the ranks
+                hs["string_ids_first_search_ms"] = 1e3 * (time.perf_counter() - t0)
+                hs["string_ids"] = host_sync_latency(sidx, 20)
+                hs["string_ids_k10"] = host_sync_latency(sidx, 10)
+                hs["string_over_int_p50"] = hs["string_ids"]["p50_ms"] / hs["int_ids"]["p50_ms"]
+                t0 = time.perf_counter()
+                rb = sidx.search_batch(list(q[:64].cpu().numpy()), 20)
+                hs["string_ids_search_batch_64q_ms"] = 1e3 * (time.perf_counter() - t0)
+                same = idx.search_batch(list(q[:64].cpu().numpy()), 20)
+                hs["string_and_int_lists_agree"] = bool(all([int(r_["id"].split("_")[0][5:]) * per_video + int(r_["id"].split("_")[1]) for r_ in a] == [r_["id"] for r_ in b]
+                                                            for a, b in zip(rb, same)))
+                lat["q1_host_sync"] = hs
+                sidx.close()
+                del sidx
+            except Exception as e:                                       # never lose the line over a secondary leg
+                lat["q1_host_sync"] = {"error": repr(e)}
+        # CPU work of the search leg (rank 0): deferred until every GPU leg has run, so the GPU legs are contiguous on the box's
+        # clock.  What it needs is copied to the host now: the matrix, the queries, and the GPU's lists for the first 256 queries
+        # (this rank's own scan of its own rows: at N > 1 the CPU legs see rank 0's shard).
+        if rank == 0 and not args.no_cpu_baseline:
             ncpu_q = 256
-            t0 = time.perf_counter()
-            knn_oracle.topk(host_rows, qs_host[:ncpu_q], k)
-            ct = time.perf_counter() - t0
-            srch["cpu_checker"] = {"value": ncpu_q / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
-                                   "sample": f"{ncpu_q} queries, exact top-{k} over {scope} {n_rows} rows, C oracle "
-                                             f"(oracle/knn_oracle.c, fp64-chain dot, OpenMP) - the parity checker, {ct:.2f}s"}
-            hn = 2000
-            _random.seed(0)
-            ho = hnsw_oracle.HnswOracle(dimq)
-            t0 = time.perf_counter(); ho.add_batch(list(host_rows[:hn]), list(range(hn))); tb = time.perf_counter() - t0
-            t0 = time.perf_counter(); [ho.search(v, k) for v in qs_host[:256]]; tq = time.perf_counter() - t0
-            srch["cpu_hnsw_port"] = {"rows": hn, "insert_ms": 1e3 * tb / hn, "queries_per_s": 256 / tq, "cores": 1,
-                                     "note": "pure-Python restatement of the reference's HNSW (oracle/hnsw_oracle.py), "
-                                             "defaults M=16 efC=200 ef=50; the reference cannot be built at 1M rows in "
-                                             "bounded time (~3 ms per insert and rising)"}
-            del host_rows
+            l_ids = torch.empty((ncpu_q, k), dtype=torch.int32, device=dev)
+            l_dd = torch.empty((ncpu_q, k), dtype=torch.float32, device=dev)
+            idx.search_device(q.data_ptr(), ncpu_q, k, l_ids.data_ptr(), l_dd.data_ptr())
+            idx.synchronize()
+            search_host = {"rows": idx._export(), "queries": q[:512].cpu().numpy(), "gpu_ids": l_ids.cpu().numpy(), "gpu_dist": l_dd.cpu().numpy(),
+                           "stats": idx.last_search_stats()}
+
+            def search_cpu_legs(h=search_host, srch=srch, n_rows=n_rows, nq=nq, k=k, dimq=dimq):
+                from oracle import hnsw_oracle, knn_oracle
+                import random as _random
+                host_rows, qs_host = h["rows"], h["queries"]
+                scope = "all" if world == 1 else "rank 0's shard of"      # N > 1: the CPU leg scans one shard, the GPU number is the whole matrix
+                ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VQ_BENCH_CPU_THREADS", "16")))
+                os.environ["OMP_NUM_THREADS"] = str(ncores)
+                try:
+                    from threadpoolctl import threadpool_limits
+                    blas_ctx = threadpool_limits(limits=ncores)
+                except ImportError:
+                    import contextlib
+                    blas_ctx = contextlib.nullcontext()
+                with blas_ctx:
+                    nb = 256
+                    t0 = time.perf_counter()
+                    sims = host_rows @ qs_host[:nb].T                                   # [N, nb] fp32 sgemm
+                    part = np.argpartition(-sims, k, axis=0)[:k]
+                    top = np.take_along_axis(part, np.argsort(-np.take_along_axis(sims, part, 0), axis=0), 0)
+                    ct = time.perf_counter() - t0
+                srch["cpu_baseline"] = {"value": nb / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
+                                        "sample": f"{nb} of the {nq} queries in one numpy fp32 sgemm over {scope} {n_rows} rows + "
+                                                  f"argpartition top-{k} (brute force as video_search_overhaul.py:54 computes it), {ct:.2f}s",
+                                        "agrees_with_gpu_top1": float(np.mean(top[0] == h["gpu_ids"][:nb, 0]))}
+                del sims
+                ncpu = h["gpu_ids"].shape[0]
+                t0 = time.perf_counter()
+                oid, od = knn_oracle.topk(host_rows, qs_host[:ncpu], k)
+                ct = time.perf_counter() - t0
+                srch["cpu_checker"] = {"value": ncpu / ct, "unit": "queries/s", "cores": ncores, "kind": "port",
+                                       "sample": f"{ncpu} queries, exact top-{k} over {scope} {n_rows} rows, C oracle "
+                                                 f"(oracle/knn_oracle.c, fp64-chain dot, OpenMP) - the parity checker, {ct:.2f}s"}
+                # the checker's lists against the GPU's for the same queries (this result used to be thrown away)
+                same_q = np.all(oid == h["gpu_ids"], axis=1)
+                srch["parity"] = {"checker": "oracle/knn_oracle.c exact top-k over the exported matrix", "queries": int(ncpu), "k": int(k),
+                                  "rows": int(n_rows), "ids_identical": bool(same_q.all()), "queries_with_identical_ids": int(same_q.sum()),
+                                  "distances_bit_identical": bool(np.array_equal(od, h["gpu_dist"])),
+                                  "max_abs_dist_diff": float(np.abs(od - h["gpu_dist"]).max()),
+                                  "gpu_search_stats": h["stats"]}
+                srch["recall_at_10"] = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(h["gpu_ids"].tolist(), oid.tolist())]))
+                hn = 2000
+                _random.seed(0)
+                ho = hnsw_oracle.HnswOracle(dimq)
+                t0 = time.perf_counter(); ho.add_batch(list(host_rows[:hn]), list(range(hn))); tb = time.perf_counter() - t0
+                t0 = time.perf_counter(); [ho.search(v, k) for v in qs_host[:256]]; tq = time.perf_counter() - t0
+                srch["cpu_hnsw_port"] = {"rows": hn, "insert_ms": 1e3 * tb / hn, "queries_per_s": 256 / tq, "cores": 1,
+                                         "note": "pure-Python restatement of the reference's HNSW (oracle/hnsw_oracle.py), "
+                                                 "defaults M=16 efC=200 ef=50; the reference cannot be built at 1M rows in "
+                                                 "bounded time (~3 ms per insert and rising); its recall against the exact list, "
+                                                 "measured on the REAL class: tests/golden/knn_ref_*.npz"}
+                h.clear()
+            cpu_legs.append(search_cpu_legs)
         out["search"] = srch
         idx.close()
 
@@ -774,28 +886,37 @@ def main():
         fx = FeatureExtractor(model_name="seed:1234", device=f"cuda:{local}", batch_size=32, device_batch=BATCH, compute_dtype=args.dtype)
         fx.extract_from_video_frames(fds[:2048])                        # warm-up: staging buffers, both handles
         best = None
-        for _ in range(2):
-            eidx = OptimizedHNSWIndex(dimension=cfg.proj_dim, device=local)
-            t0 = time.perf_counter()
-            feats = fx.extract_from_video_frames(fds)
-            t1 = time.perf_counter()
-            eidx.add_batch([o["features"] for o in feats], list(range(len(feats))))
-            t2 = time.perf_counter()
-            res = eidx.search_batch([o["features"] for o in feats[:64]], 10)
-            t3 = time.perf_counter()
-            assert len(res) == 64 and res[0][0]["distance"] <= 1e-6        # a stored frame finds itself
-            eidx.close()
-            cur = {"frames": len(fds), "extract_s": t1 - t0, "add_batch_s": t2 - t1, "search_64q_s": t3 - t2,
-                   "extract_frames_per_s": len(fds) / (t1 - t0), "frames_per_s": len(fds) / (t3 - t0)}
-            if best is None or cur["frames_per_s"] > best["frames_per_s"]:
-                best = cur
-        best["path"] = ("host uint8 frame dicts -> FeatureExtractor.extract_from_video_frames (2 ingest handles, pinned staging, H2D) -> "
-                        "OptimizedHNSWIndex.add_batch -> search_batch(64 queries, k=10); best of 2 passes")
+        try:
+            names = [f"video{i // 2048}_{i % 2048}" for i in range(len(fds))]      # the caller's ids (video_search_system.py:164-166)
+            for _ in range(2):
+                eidx = OptimizedHNSWIndex(dimension=cfg.proj_dim, device=local)
+                t0 = time.perf_counter()
+                feats = fx.extract_from_video_frames(fds)
+                t1 = time.perf_counter()
+                eidx.add_batch([o["features"] for o in feats], names)
+                t2 = time.perf_counter()
+                res = eidx.search_batch([o["features"] for o in feats[:64]], 10)
+                t3 = time.perf_counter()
+                one = [eidx.search(o["features"], 20) for o in feats[:64]]     # ... and the caller's own call (:297), one at a time
+                t4 = time.perf_counter()
+                # a stored frame finds itself; the 1,024 distinct frames are stored 8 times each: eight-way ties, returned in id order
+                self_ok = bool(len(res) == 64 and res[0][0]["distance"] <= 1e-6 and [r["id"] for r in one[0][:8]] == sorted(r["id"] for r in one[0][:8]))
+                eidx.close()
+                cur = {"frames": len(fds), "extract_s": t1 - t0, "add_batch_s": t2 - t1, "search_64q_s": t3 - t2, "search_64_single_calls_s": t4 - t3,
+                       "extract_frames_per_s": len(fds) / (t1 - t0), "frames_per_s": len(fds) / (t3 - t0), "self_match_and_tie_order_ok": self_ok}
+                if best is None or cur["frames_per_s"] > best["frames_per_s"]:
+                    best = cur
+            best["path"] = ("host uint8 frame dicts -> FeatureExtractor.extract_from_video_frames (2 ingest handles, pinned staging, H2D) -> "
+                            "OptimizedHNSWIndex.add_batch under string ids f\"video{v}_{i}\" -> search_batch(64 queries, k=10) [-> 64 x search(q, 20)]; best of 2 passes")
+        except Exception as e:                                              # a secondary leg: the headline line is printed whatever happens here
+            best = {"error": repr(e)}
         out["e2e_host"] = best
-        out["e2e_host_frames_per_s"] = best["frames_per_s"]
+        out["e2e_host_frames_per_s"] = best.get("frames_per_s")
         fx.thread_pool.shutdown()
         del fx, fds, distinct
 
+    for leg in cpu_legs:
+        leg()
     # ---- CPU baseline: the fp32 oracle (a port of the reference's CPU path) on a bounded sample ----
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import clip_vit_oracle

@@ -200,9 +200,20 @@ int vq_index_add_device(vq_index* idx, const void* d_rows_f32, int64_t n, int no
 int vq_index_update_rows(vq_index* idx, const float* rows, const int64_t* row_numbers, int64_t n, int normalize);
 int vq_index_size(vq_index* idx, int64_t* n);
 int vq_index_clear(vq_index* idx);
+/* The tie order of the result lists.  The reference returns `sorted(candidates)[:k]` over (distance, id) tuples
+ * (hnsw.py:269, :518): rows at EQUAL distance (duplicate frames) come back in the order of the caller's ids — strings
+ * f"{video_id}_{i}" under video_search_system.py:164-166, where "video0_10" sorts before "video0_2".  The library sees row
+ * numbers only, so the host hands it rank_of_row[r] = position of row r's id in the caller's id order (a permutation of
+ * 0..n-1, n = the current size; checked).  Every search then selects and orders by (dist, rank) on the device and still
+ * reports ROW numbers.  n = 0 (rank_of_row may be NULL) returns to (dist, row) order.  Ranks describe the rows present when
+ * they were set: after vq_index_add* a search is refused (VQ_ERR_INVALID) until the ranks are set again or cleared;
+ * vq_index_update_rows keeps them (same ids), vq_index_clear drops them.  Synchronous.  vq_index_search_sharded orders
+ * ties ACROSS shards by global row number whatever the shards' ranks say. */
+int vq_index_set_id_ranks(vq_index* idx, const int32_t* rank_of_row, int64_t n);
 
 /* search / search_batch (hnsw.py:238-300, 488-528) as an exact scan:
- *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row).
+ *   dist = fp32(1 - fp32(dot(row, q))), k smallest, ordered by (dist, row) — or (dist, id rank) once
+ *   vq_index_set_id_ranks has been called.
  * queries [nq][dim] are used as given (the wrapper does query / ||query|| with numpy, hnsw.py:250).  The
  * fp16 path's exactness bound scales with each query's own norm while 0.25 <= |q|^2 <= 4; a query outside that
  * range (or not finite) is outside what fp16 operands can bound and is answered by the exact scan instead

@@ -74,6 +74,35 @@ def gpu_lib():
     return _lib
 
 
+# ---- the configs[2] pin against the REAL reference above N = 1,000 (tests/golden/knn_ref_<n>.npz) ----
+KNN_BIG_SEED = 20251005
+KNN_BIG_DUPES = ((2, 10), (3, 20, 100), (777, 5000))      # groups of rows made exact duplicates of the first one
+
+
+def knn_big_ids(n):
+    """The ids the reference's caller builds: f"{video_id}_{i}" (src/video_search_system.py:164-166), four videos."""
+    per = n // 4
+    return [f"video{r // per}_{r % per}" for r in range(n)]
+
+
+def knn_big_inputs(n, nq=64):
+    """SURVEY.md §8(d) config 3's recipe at prefix size: `standard_normal` fp32 rows (normalised by `add`), queries from a
+    different seed.  Planted: groups of exact duplicate rows whose string ids sort differently from their row numbers
+    ("video0_10" < "video0_2"), and queries next to them, so the (distance, id) tie rule of hnsw.py:269/518 is exercised
+    with the caller's ids against the real class."""
+    rows = np.random.default_rng(KNN_BIG_SEED).standard_normal((n, 512)).astype(np.float32)
+    for grp in KNN_BIG_DUPES:
+        for r in grp[1:]:
+            if r < n and grp[0] < n:
+                rows[r] = rows[grp[0]]
+    qrng = np.random.default_rng(KNN_BIG_SEED + 1)
+    qs = qrng.standard_normal((nq, 512)).astype(np.float32)
+    for j, grp in enumerate(KNN_BIG_DUPES):
+        if grp[0] < n:
+            qs[j] = rows[grp[0]] + np.float32(0.05) * qrng.standard_normal(512).astype(np.float32)
+    return rows, qs
+
+
 # ---- resize fixtures (tests/golden/resample_pil.npz; inputs are regenerated from the seed) ----
 RESAMPLE_SEED = 31337
 RESAMPLE_CASES = [            # (name, h, w, kind, mode)   kind: noise | smooth ; mode: stretch | clip

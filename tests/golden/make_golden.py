@@ -21,6 +21,13 @@ Produces
   ref_index_50.pkl(.sha256), ref_index_50_results.npz, simple_index.npz, ref_simple_index_cache.pkl
                              (`make_golden.py interop`) files WRITTEN by the real reference classes and the result
                              lists the real classes return (persistence / live-index fixtures).
+  knn_ref_10000.npz, knn_ref_100000.npz
+                             (`make_golden.py knn_big 10000`, `... knn_big 100000`) the REAL OptimizedHNSWIndex over a
+                             10k / 100k-row prefix of configs[2]'s recipe, built under the caller's STRING ids
+                             (video_search_system.py:164-166) with planted exact-duplicate rows: its top-10 / top-20
+                             lists (as row numbers) and distances for 64 queries at ef_search = 50 (default) and
+                             ef_search = N (exhaustive), the exact lists of the C oracle beside them, and the
+                             default-ef recall against the exact lists.  Rows regenerate from the seed.
   knn_cfg1.npz               the REAL reference index (src/indexes/hnsw.py
                              OptimizedHNSWIndex, random.seed(0)) over 1,000
                              seeded vectors: its levels, entry point and graph,
@@ -186,7 +193,8 @@ def capture_text_l14():
 
 
 sys.path.insert(0, os.path.dirname(HERE))
-from conftest import RESAMPLE_CASES, RESAMPLE_SEED, resample_input    # noqa: E402  (shared with the tests)
+from conftest import (RESAMPLE_CASES, RESAMPLE_SEED, resample_input,    # noqa: E402  (shared with the tests)
+                      KNN_BIG_SEED, knn_big_ids, knn_big_inputs)
 
 
 def capture_resample():
@@ -237,6 +245,59 @@ def capture_knn(queries):
             out[f"score_ef{ef}_k{k}"] = np.array([[r["score"] for r in rr] for rr in res], dtype=np.float32)
             assert all(type(r["distance"]) is np.float32 for rr in res for r in rr)
     np.savez_compressed(os.path.join(HERE, "knn_cfg1.npz"), **out)
+
+
+def capture_knn_big(n):
+    """VERDICT r03 #1: the configs[2] / recall claim pinned against the real class above N = 1,000."""
+    import time
+    sys.path.insert(0, "/root/reference/src")
+    from indexes.hnsw import OptimizedHNSWIndex        # the real reference
+    from oracle import knn_oracle
+
+    rows, qs = knn_big_inputs(n)
+    ids = knn_big_ids(n)
+    row_of = {s_: r for r, s_ in enumerate(ids)}
+    random.seed(0)
+    idx = OptimizedHNSWIndex(dimension=512)            # defaults: M=16 efC=200 ef=50 (video_search_system.py:79-89)
+    t0 = time.time()
+    for c0 in range(0, n, 5000):
+        idx.add_batch(list(rows[c0:c0 + 5000]), ids[c0:c0 + 5000])
+        print(f"  built {min(c0 + 5000, n)} rows, {time.time() - t0:.0f}s", flush=True)
+    build_s = time.time() - t0
+    stored = np.stack([idx.data[s_] for s_ in ids]).astype(np.float32)
+    unit_q = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    ex_rows, ex_dist = knn_oracle.topk(stored, unit_q, 20)     # exact lists by ROW on ties; ties re-ordered by id below
+    out = dict(seed=KNN_BIG_SEED, n=n, build_seconds=np.float32(build_s),
+               stored_sha256=hashlib.sha256(stored.tobytes()).hexdigest(),
+               stored_head=stored[:64].copy(), stored_tail=stored[-64:].copy())
+    for ef in (50, n):
+        idx.ef_search = ef
+        for k in (10, 20):
+            t0 = time.time()
+            res = [idx.search(q, k) for q in qs]
+            dt = time.time() - t0
+            assert all(len(rr) == k for rr in res)
+            out[f"rows_ef{ef}_k{k}"] = np.array([[row_of[r["id"]] for r in rr] for rr in res], dtype=np.int32)
+            out[f"dist_ef{ef}_k{k}"] = np.array([[r["distance"] for r in rr] for rr in res], dtype=np.float32)
+            out[f"ms_per_query_ef{ef}_k{k}"] = np.float32(1e3 * dt / len(qs))
+            print(f"  ef={ef} k={k}: {1e3 * dt / len(qs):.1f} ms/query", flush=True)
+    # the exact answer in the reference's order: (distance, id string)
+    exact = []
+    for j in range(len(qs)):
+        cand = sorted((ex_dist[j, i], ids[ex_rows[j, i]]) for i in range(20))
+        exact.append([row_of[s_] for _, s_ in cand])
+    exact = np.array(exact, dtype=np.int32)
+    out["rows_exact_k20"] = exact
+    out["dist_exact_k20"] = ex_dist
+    for k in (10, 20):
+        got = out[f"rows_ef{n}_k{k}"]
+        # a top-k prefix of the exact top-20 is only tie-safe when no tie group straddles rank k; the planted groups sit at ranks 1-3
+        out[f"exhaustive_lists_identical_k{k}"] = np.int32(sum(np.array_equal(got[j], exact[j, :k]) for j in range(len(qs))))
+        dflt = out[f"rows_ef50_k{k}"]
+        out[f"default_ef_recall_k{k}"] = np.float32(np.mean([len(set(dflt[j]) & set(exact[j, :k])) / k for j in range(len(qs))]))
+        print(f"  k={k}: exhaustive lists identical to the exact answer for {out[f'exhaustive_lists_identical_k{k}']}/{len(qs)} "
+              f"queries; default-ef recall {out[f'default_ef_recall_k{k}']:.4f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, f"knn_ref_{n}.npz"), **out)
 
 
 INTEROP_SEED, INTEROP_N = 11, 50
@@ -316,6 +377,9 @@ def capture_interop():
 
 
 if __name__ == "__main__":
+    if "knn_big" in sys.argv[1:]:
+        capture_knn_big(int(sys.argv[sys.argv.index("knn_big") + 1]))
+        sys.exit(0)
     if "interop" in sys.argv[1:]:
         capture_interop()
         sys.exit(0)

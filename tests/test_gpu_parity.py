@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import INDEX_SEED, synth_frames
+from conftest import GOLDEN, INDEX_SEED, synth_frames
 from oracle import clip_vit_oracle, knn_oracle
 
 pytestmark = pytest.mark.gpu
@@ -297,6 +297,57 @@ def test_index_config1_matches_reference_and_oracle(gpu_lib, golden_knn, golden_
     idx.thread_pool.shutdown()
 
 
+@pytest.mark.parametrize("n", [10_000, 100_000])
+def test_index_matches_the_real_reference_above_1k_rows_with_the_callers_string_ids(gpu_lib, n):
+    """configs[2] / north_star "top-k recall@10 = 1.0 vs reference", pinned against the REAL OptimizedHNSWIndex at 10k and 100k
+    rows (tests/golden/knn_ref_<n>.npz, `make_golden.py knn_big <n>`: config 3's recipe at prefix size, built in the
+    container under the caller's string ids, with planted duplicate frames).  The reference at ef_search = N is exhaustive
+    (64/64 of its lists equal the exact answer); the drop-in, called the way video_search_system.py:164-181, :297 calls it
+    — one add_batch per video, string ids, one query at a time, k*2 results — returns the identical id lists."""
+    import hashlib
+    from conftest import knn_big_ids, knn_big_inputs
+    from video_quierer_amd.indexes.hnsw import MODE_FP16, OptimizedHNSWIndex
+    path = os.path.join(GOLDEN, f"knn_ref_{n}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not captured")
+    ref = np.load(path)
+    rows, qs = knn_big_inputs(n)
+    ids = knn_big_ids(n)
+    row_of = {s: r for r, s in enumerate(ids)}
+    idx = OptimizedHNSWIndex(dimension=512, M=16, ef_construction=200, ef_search=50, max_M=16)
+    per = n // 4
+    for v in range(4):                                                    # one add_batch per video (video_search_system.py:181)
+        idx.add_batch(rows[v * per:(v + 1) * per], ids[v * per:(v + 1) * per])
+    stored = idx._export()
+    assert hashlib.sha256(stored.tobytes()).hexdigest() == str(ref["stored_sha256"])      # stored rows == the reference's .data, all of them
+    assert np.array_equal(stored[:64], ref["stored_head"]) and np.array_equal(stored[-64:], ref["stored_tail"])
+    unit_q = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
+    modes = (idx.search_mode,) if n >= 16384 else (idx.search_mode, MODE_FP16)       # 10k rows: auto = the exact scan; force the fp16 path too
+    for mode in modes:
+        idx.search_mode = mode
+        for k in (10, 20):
+            one = [idx.search(q, k) for q in qs]                          # the caller's call: one query at a time (:297)
+            got = np.array([[row_of[r["id"]] for r in rr] for rr in one], dtype=np.int32)
+            d = np.array([[r["distance"] for r in rr] for rr in one], dtype=np.float32)
+            assert np.array_equal(got, ref[f"rows_ef{n}_k{k}"]), (mode, k)                 # identical lists vs the exhaustive reference
+            assert np.abs(d - ref[f"dist_ef{n}_k{k}"]).max() <= 3e-7
+            assert np.array_equal(got, ref["rows_exact_k20"][:, :k])                       # == the exact answer in (distance, id) order
+            assert np.array_equal(d, ref["dist_exact_k20"][:, :k])                         # bit-exact vs the C oracle's distances
+            recall = np.mean([len(set(got[j]) & set(ref[f"rows_ef{n}_k{k}"][j])) / k for j in range(len(qs))])
+            assert recall == 1.0
+            batch = idx.search_batch(list(qs), k)
+            assert [[r["id"] for r in rr] for rr in batch] == [[r["id"] for r in rr] for rr in one]
+            assert type(one[0][0]["distance"]) is np.float32 and type(one[0][0]["id"]) is str
+    # the planted duplicate frames head their queries' lists in STRING order: "video0_10" before "video0_2"
+    assert [r["id"] for r in idx.search(qs[0], 10)[:2]] == ["video0_10", "video0_2"]
+    assert [r["id"] for r in idx.search(qs[1], 10)[:3]] == ["video0_100", "video0_20", "video0_3"]
+    for k in (10, 20):
+        print(f"N={n}: reference default-ef (50) recall@{k} against the exact list = {float(ref[f'default_ef_recall_k{k}']):.4f} "
+              f"({float(ref[f'ms_per_query_ef50_k{k}']):.1f} ms/query; exhaustive ef=N: {float(ref[f'ms_per_query_ef{n}_k{k}']):.0f} ms/query); "
+              f"this build: 1.0000")
+    idx.close()
+
+
 def test_index_edge_cases(gpu_lib, tmp_path):
     from video_quierer_amd.indexes.hnsw import HNSWIndex, OptimizedHNSWIndex
     rng = np.random.default_rng(5)
@@ -578,20 +629,41 @@ def test_config4_end_to_end_on_one_gpu(gpu_lib):
 
 
 # ------------------------------------------------------------------ fp16 MFMA scan + exact re-score
-def _scan_vs_oracle(vecs, qs, k, expect_fallback=None):
+def _expected_in_id_order(stored, unit_q, ids, k):
+    """What the reference returns once its walk is exhaustive: ``sorted((distance, id) ...)[:k]`` (hnsw.py:269 / :518) over the
+    oracle's exact distances — the ids compared as Python compares them, only where distances tie."""
+    out = []
+    for q in unit_q:
+        d = knn_oracle.distances(stored, q)
+        kth = np.partition(d, min(k, len(d)) - 1)[min(k, len(d)) - 1]
+        cand = np.nonzero(d <= kth)[0]                                   # every row that can be in the list, tie groups whole
+        out.append(sorted((d[r], ids[r]) for r in cand)[:k])
+    return out
+
+
+def _scan_vs_oracle(vecs, qs, k, expect_fallback=None, ids=None, mode=None):
+    """ids=None: integer ids = row numbers, compared with the C oracle's (distance, row) lists.  ids given (the caller's
+    strings, video_search_system.py:164-166): compared with the (distance, id) order built from the oracle's distances."""
     from video_quierer_amd.indexes.hnsw import MODE_FP16, OptimizedHNSWIndex
     idx = OptimizedHNSWIndex(dimension=vecs.shape[1])
-    idx.add_batch(list(vecs), list(range(len(vecs))))
-    idx.search_mode = MODE_FP16
-    res = idx.search_batch(list(qs), k)
+    idx.add_batch(list(vecs), list(range(len(vecs))) if ids is None else list(ids))
+    idx.search_mode = MODE_FP16 if mode is None else mode
+    res = idx.search_batch(list(qs), k) if len(qs) != 1 else [idx.search(qs[0], k)]
     st = idx.last_search_stats()
     stored = idx._export()
     uq = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)
-    oid, od = knn_oracle.topk(stored, uq, k)
-    ids = np.array([[r["id"] for r in rr] + [-1] * (k - len(rr)) for rr in res], dtype=np.int32)
-    d = np.array([[r["distance"] for r in rr] + [np.inf] * (k - len(rr)) for rr in res], dtype=np.float32)
-    assert np.array_equal(ids, oid), f"ids differ from the oracle (stats {st})"
-    assert np.array_equal(d, od), f"distances differ from the oracle (stats {st})"
+    if ids is not None:
+        assert idx._tie_order == "device"
+        want = _expected_in_id_order(stored, uq, ids, k)
+        for j, (rr, ww) in enumerate(zip(res, want)):
+            assert [r["id"] for r in rr] == [i for _, i in ww], f"query {j}: ids differ from the (distance, id) order (stats {st})"
+            assert [r["distance"] for r in rr] == [d for d, _ in ww], f"query {j}: distances differ from the oracle (stats {st})"
+    else:
+        oid, od = knn_oracle.topk(stored, uq, k)
+        got = np.array([[r["id"] for r in rr] + [-1] * (k - len(rr)) for rr in res], dtype=np.int32)
+        d = np.array([[r["distance"] for r in rr] + [np.inf] * (k - len(rr)) for rr in res], dtype=np.float32)
+        assert np.array_equal(got, oid), f"ids differ from the oracle (stats {st})"
+        assert np.array_equal(d, od), f"distances differ from the oracle (stats {st})"
     assert st["verified"] + st["rescanned"] + st["exact_fallback"] == len(qs)
     idx.close()
     return st
@@ -675,6 +747,74 @@ def test_fp16_scan_clustered_and_degenerate_data_stay_exact(gpu_lib):
     assert st["exact_fallback"] == 301
     st = _scan_vs_oracle(same[:16385], same[:70] + 0, 3)      # batch path (> 64 queries), 9 row splits of 2048 with a 1-row tail
     assert st["exact_fallback"] == 70
+
+
+def test_tie_order_follows_the_callers_ids_on_every_search_path(gpu_lib):
+    """hnsw.py:269 / :518 sort (distance, id) tuples, and the caller's ids are strings f"{video_id}_{i}"
+    (video_search_system.py:164-166): duplicate frames come back in STRING order ("video0_10" before "video0_2"), which is
+    not row order.  The device orders by (distance, rank of the id) itself (vq_index_set_id_ranks) — checked here on every
+    path a search can take: the exact scan, the single-query / small-batch / MFMA-tile fp16 scans with their 32-, 80- and
+    128-candidate re-score kernels, stream rescans, and the device-side exact fallback."""
+    from video_quierer_amd.indexes.hnsw import MODE_EXACT, MODE_FP16
+    from conftest import knn_big_ids
+    rng = np.random.default_rng(47)
+    base = rng.standard_normal((6000, 256)).astype(np.float32)
+    tied = np.concatenate([base] * 3)                                   # every row three times, 6,000 rows apart
+    ids = knn_big_ids(len(tied))                                        # "video0_0" ... "video3_4499"
+    qs = np.concatenate([base[:200] + 0, rng.standard_normal((120, 256)).astype(np.float32)])
+    for mode in (MODE_EXACT, MODE_FP16):
+        for nq, k in ((1, 2), (1, 10), (1, 20), (1, 32), (5, 10), (33, 7), (33, 40), (97, 10), (320, 4), (130, 20), (130, 64), (100, 100)):
+            _scan_vs_oracle(tied, qs[:nq], k, ids=ids, mode=mode)
+    # tie groups larger than any candidate pool: nothing can be proven, the exact fallback orders by id rank too
+    same = np.tile(rng.standard_normal((1, 128)).astype(np.float32), (16400, 1))
+    same[::5] *= 1.0 + 1e-7 * rng.standard_normal((len(same[::5]), 1)).astype(np.float32)
+    sids = knn_big_ids(len(same))
+    for nq, k in ((1, 5), (3, 32), (70, 3), (301, 10)):
+        st = _scan_vs_oracle(same, same[:nq] + 0, k, ids=sids, mode=MODE_FP16)
+        assert st["exact_fallback"] == nq, st
+    # integer ids that are not the row numbers (reversed): ties by the smaller INTEGER, i.e. the later row
+    rev = list(range(len(tied) - 1, -1, -1))
+    _scan_vs_oracle(tied, qs[:40], 10, ids=rev, mode=MODE_FP16)
+    _scan_vs_oracle(tied, qs[:1], 10, ids=rev, mode=MODE_EXACT)
+
+
+def test_id_ranks_c_abi_contract(gpu_lib):
+    """vq_index_set_id_ranks through the C ABI: a non-permutation is refused, ranks go stale when rows are added (the next
+    search fails loudly instead of ordering ties by garbage), n = 0 restores row order, vq_index_update_rows keeps them."""
+    from ctypes import POINTER, byref, c_float, c_int32, c_int64, c_void_p
+    lib = gpu_lib.load()
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((40, 64)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[30] = rows[7]                                                  # one tie
+    h = c_void_p()
+    gpu_lib.check(lib.vq_index_create(64, byref(h)))
+    gpu_lib.check(lib.vq_index_add(h, gpu_lib.fptr(rows), 40, 0))
+    ids, dist = np.empty((1, 3), np.int32), np.empty((1, 3), np.float32)
+
+    def search():
+        return lib.vq_index_search(h, gpu_lib.fptr(rows[7:8].copy()), 1, 3, 0, ids.ctypes.data_as(POINTER(c_int32)), gpu_lib.fptr(dist))
+    gpu_lib.check(search())
+    assert list(ids[0, :2]) == [7, 30]                                  # row order
+    rank = np.arange(40, dtype=np.int32)[::-1].copy()                   # reversed id order: row 30's id sorts first
+    gpu_lib.check(lib.vq_index_set_id_ranks(h, rank.ctypes.data_as(POINTER(c_int32)), 40))
+    gpu_lib.check(search())
+    assert list(ids[0, :2]) == [30, 7] and dist[0, 0] == dist[0, 1]
+    bad = rank.copy(); bad[3] = bad[4]
+    assert lib.vq_index_set_id_ranks(h, bad.ctypes.data_as(POINTER(c_int32)), 40) < 0 and b"permutation" in lib.vq_last_error()
+    assert lib.vq_index_set_id_ranks(h, rank.ctypes.data_as(POINTER(c_int32)), 39) < 0
+    gpu_lib.check(search())                                             # a refused call leaves the old ranks in place
+    assert list(ids[0, :2]) == [30, 7]
+    rn = (c_int64 * 1)(12)
+    gpu_lib.check(lib.vq_index_update_rows(h, gpu_lib.fptr(rows[5:6].copy()), rn, 1, 0))      # same ids: ranks stay valid
+    gpu_lib.check(search())
+    assert list(ids[0, :2]) == [30, 7]
+    gpu_lib.check(lib.vq_index_add(h, gpu_lib.fptr(rows[:2].copy()), 2, 0))
+    assert search() < 0 and b"id ranks" in lib.vq_last_error()          # stale: refused
+    gpu_lib.check(lib.vq_index_set_id_ranks(h, None, 0))
+    gpu_lib.check(search())
+    assert list(ids[0, :2]) == [7, 30]                                  # back to row order
+    gpu_lib.check(lib.vq_index_destroy(h))
 
 
 # ------------------------------------------------------------------ live system's brute-force index ("next" #2)
@@ -1108,10 +1248,10 @@ def test_feature_extractor_text_ids(gpu_lib):
 
 # ------------------------------------------------------------------ BASELINE full sizes through size-independent properties
 def test_config3_full_size_properties(gpu_lib):
-    """configs[2]: 1,000,000 x 512 matrix.  Too large for the CPU oracle in seconds, so: (a) self-queries
-    return their own row first at distance ~0, (b) lists are sorted by (distance, id), (c) the fp16-scan
-    result is bit-identical to the independent exact fp32-master scan on a query subset, (d) every query is
-    accounted for by the proof statistics."""
+    """configs[2]: 1,000,000 x 512 matrix.  (a) self-queries return their own row first at distance ~0, (b) lists are
+    sorted by (distance, id), (c) the fp16-scan result is bit-identical to the independent exact fp32-master scan on a
+    query subset, (d) every query is accounted for by the proof statistics, (e) 64 queries x k = 10 are bit-exact
+    against the C oracle over the exported 1M rows on every scan path (one query, 33, 64, the 256-query MFMA tile)."""
     import torch
     from video_quierer_amd.indexes.hnsw import MODE_EXACT, MODE_FP16, OptimizedHNSWIndex
     n, d = 1_000_000, 512
@@ -1148,6 +1288,25 @@ def test_config3_full_size_properties(gpu_lib):
         idx.search_device(more.data_ptr(), nq, 10, b_i.data_ptr(), b_d.data_ptr(), mode=MODE_EXACT); idx.synchronize()
         assert torch.equal(a_i, b_i) and torch.equal(a_d, b_d), nq
         assert st["verified"] + st["rescanned"] + st["exact_fallback"] == nq and st["exact_fallback"] <= 1, (nq, st)
+    # HIP vs the C oracle at FULL size (the comparisons above are between two HIP paths that share the row
+    # normalisation, the fp32 master and the addressing): the matrix exported once, 64 queries x k = 10 through
+    # oracle/knn_oracle.c (fp64-chain dot, seconds on the box's cores), bit-exact ids and distances on each scan path
+    host_rows = idx._export()
+    assert host_rows.shape == (n, d)
+    more_h = more[:64].cpu().numpy()
+    oid, od = knn_oracle.topk(host_rows, more_h, 10)
+    for nq in (1, 33, 64):
+        a_i = torch.empty((nq, 10), dtype=torch.int32, device=dev); a_d = torch.empty((nq, 10), device=dev)
+        idx.search_device(more.data_ptr(), nq, 10, a_i.data_ptr(), a_d.data_ptr(), mode=MODE_FP16); idx.synchronize()
+        assert np.array_equal(a_i.cpu().numpy(), oid[:nq]) and np.array_equal(a_d.cpu().numpy(), od[:nq]), nq
+    a_i = torch.empty((300, 10), dtype=torch.int32, device=dev); a_d = torch.empty((300, 10), device=dev)
+    idx.search_device(more.data_ptr(), 300, 10, a_i.data_ptr(), a_d.data_ptr(), mode=MODE_FP16); idx.synchronize()      # the MFMA-tile scan
+    assert np.array_equal(a_i.cpu().numpy()[:64], oid) and np.array_equal(a_d.cpu().numpy()[:64], od)
+    # ... and the rows the device normalised are the oracle's normalisation of the same raw rows (first block)
+    g0 = torch.Generator(device=dev); g0.manual_seed(123)
+    raw = torch.randn((250_000, d), device=dev, generator=g0)[:4096].cpu().numpy()
+    assert np.array_equal(host_rows[:4096], knn_oracle.normalize_rows(raw))
+    del host_rows
     # the caller's over-fetch (k * 2, video_search_system.py:297) for user k up to 32: k in (20, 64] stays on the fp16 scans
     # (80- / 128-candidate re-score pools up to k = 100: the API's k <= 50) and closes its proofs at this size
     for nq, k in ((1, 20), (1, 32), (1, 64), (33, 24), (300, 32), (300, 64), (1, 100), (300, 100)):

@@ -89,6 +89,35 @@ def test_exact_oracle_equals_exhaustive_reference(golden_knn, golden_encoder):
     assert 0.5 < rec < 1.0
 
 
+def test_exact_oracle_equals_the_exhaustive_reference_at_10k_and_100k_rows():
+    """tests/golden/knn_ref_<n>.npz (the REAL OptimizedHNSWIndex over 10k / 100k seeded rows under the caller's string ids):
+    the inputs regenerate from the seed to the rows the reference stored, the reference at ef_search = N returned the
+    exact answer for every query, and the C oracle + the (distance, id) tie rule reproduces its lists."""
+    import os
+    from conftest import GOLDEN, KNN_BIG_DUPES, knn_big_ids, knn_big_inputs
+    for n in (10_000, 100_000):
+        path = os.path.join(GOLDEN, f"knn_ref_{n}.npz")
+        if not os.path.exists(path):
+            continue
+        ref = np.load(path)
+        rows, qs = knn_big_inputs(n)
+        ids = knn_big_ids(n)
+        stored = np.stack([v / np.linalg.norm(v) for v in rows]).astype(np.float32)            # hnsw.py:157
+        assert hashlib.sha256(stored.tobytes()).hexdigest() == str(ref["stored_sha256"])
+        assert int(ref["exhaustive_lists_identical_k10"]) == 64 and int(ref["exhaustive_lists_identical_k20"]) == 64
+        unit_q = np.stack([q / np.linalg.norm(q) for q in qs]).astype(np.float32)              # hnsw.py:499
+        orow, od = knn_oracle.topk(stored, unit_q, 20)
+        row_of = {s: r for r, s in enumerate(ids)}
+        want = np.array([[row_of[s] for _, s in sorted((od[j, i], ids[orow[j, i]]) for i in range(20))] for j in range(64)])
+        for k in (10, 20):
+            assert np.array_equal(want[:, :k], ref[f"rows_ef{n}_k{k}"])
+            assert np.abs(od[:, :k] - ref[f"dist_ef{n}_k{k}"]).max() <= 3e-7
+            assert 0.0 < float(ref[f"default_ef_recall_k{k}"]) < 1.0       # the default walk (ef_search = 50) is approximate
+        # the planted duplicate frames: id order, not row order
+        assert list(ref[f"rows_ef{n}_k10"][0, :2]) == [10, 2] and list(ref[f"rows_ef{n}_k10"][1, :3]) == [100, 20, 3]
+        assert KNN_BIG_DUPES[0] == (2, 10)
+
+
 def test_exact_oracle_edge_cases():
     rng = np.random.default_rng(3)
     x = knn_oracle.normalize_rows(rng.standard_normal((7, 16)).astype(np.float32))

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vq_index_update_rows": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int64), c_int64, c_int]),
     "vq_index_size": (c_int, [c_void_p, POINTER(c_int64)]),
     "vq_index_clear": (c_int, [c_void_p]),
+    "vq_index_set_id_ranks": (c_int, [c_void_p, POINTER(c_int32), c_int64]),
     "vq_index_search": (c_int, [c_void_p, POINTER(c_float), c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
     "vq_index_search_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vq_index_synchronize": (c_int, [c_void_p]),

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(FB_TILE)
 void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
                            const float* __restrict__ queries, const int32_t* __restrict__ slots,
                            const int32_t* __restrict__ counters, int slot_base, int slot_cap, int k,
-                           int64_t rows_per_split, uint64_t* __restrict__ partial /*[slot_cap][splits][k]*/) {
+                           int64_t rows_per_split, uint64_t* __restrict__ partial /*[slot_cap][splits][k]*/, const TieOrder tie) {
     const int count = min(counters[0] - slot_base, slot_cap);          // flagged queries of this round (uniform)
     if (count <= 0) return;
     __shared__ float xs[FB_TILE][FB_PANEL + 1];
@@ -129,12 +129,13 @@ void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
                 __syncthreads();
             }
             const int64_t row = r0 + tid;
+            const uint32_t my_tie = row < r_end ? tie_of(tie, row) : 0u;        // (distance, id) order: TieOrder, vq_common.h
             // rows that beat the query's current k-th key join its candidate list: one LDS atomic per wave and query
             // (a wave-wide ballot places the lanes), not one per row — the first tiles of a scan accept every row
 #pragma unroll
             for (int j = 0; j < FB_QG; ++j) {
                 if (qidx[j] < 0) continue;                                           // block-uniform
-                const uint64_t key = dist_key(1.0f - (float)acc[j], (uint32_t)row);
+                const uint64_t key = dist_key(1.0f - (float)acc[j], my_tie);
                 const bool in = row < r_end && key < best[cur_s[j]][j][k - 1];
                 const unsigned long long mask = __ballot(in);
                 if (mask == 0) continue;                                             // wave-uniform
@@ -180,7 +181,7 @@ void exact_fallback_kernel(const float* __restrict__ rows, int64_t n, int dim,
 __global__ __launch_bounds__(256)
 void fallback_merge_kernel(const uint64_t* __restrict__ partial, int splits, int k, const int32_t* __restrict__ slots,
                            const int32_t* __restrict__ counters, int slot_base, int slot_cap,
-                           int32_t* __restrict__ ids, float* __restrict__ out_dist) {
+                           int32_t* __restrict__ ids, float* __restrict__ out_dist, const TieOrder tie) {
     __shared__ uint64_t red[4];
     __shared__ uint64_t head[FB_MAX_SPLITS];
     __shared__ uint8_t pos[FB_MAX_SPLITS];
@@ -204,7 +205,7 @@ void fallback_merge_kernel(const uint64_t* __restrict__ partial, int splits, int
             if (tid == 0) {
                 const int64_t o = (int64_t)q * k + j;
                 if (b == ~0ull) { ids[o] = -1; out_dist[o] = __builtin_inff(); }
-                else { ids[o] = (int32_t)(uint32_t)b; out_dist[o] = key_dist(b); }
+                else { ids[o] = tie_row(tie, (uint32_t)b); out_dist[o] = key_dist(b); }
             }
             if (b == ~0ull) {                              // every list exhausted (block-uniform)
                 for (int jj = j + 1 + tid; jj < k; jj += 256) { ids[(int64_t)q * k + jj] = -1; out_dist[(int64_t)q * k + jj] = __builtin_inff(); }

@@ -172,7 +172,7 @@ void exact_dist_kernel(const float* __restrict__ rows, int64_t n, int dim,
 // ---- exact selection ----
 // Two levels so that a large matrix is not scanned k times by one workgroup per query:
 //   select_chunk_kernel: workgroup (chunk, query) holds its 8192 distances in registers
-//     as (distance,row) keys and extracts the chunk's k smallest in k rounds of
+//     as (distance, tie) keys — tie = the row, or the rank of the row's id (TieOrder, vq_common.h) — and extracts the chunk's k smallest in k rounds of
 //     "smallest key strictly above the previous one" (keys are unique: row is in the key);
 //   merge_topk_kernel: one workgroup per query does the same over the chunks' lists.
 constexpr int SEL_CHUNK = 8192;
@@ -195,7 +195,7 @@ __device__ __forceinline__ uint64_t block_min_u64(uint64_t v, uint64_t* red /*[4
 
 __global__ __launch_bounds__(256)
 void select_chunk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k, int nchunks,
-                         uint64_t* __restrict__ partial /*[q][nchunks][k]*/) {
+                         uint64_t* __restrict__ partial /*[q][nchunks][k]*/, const TieOrder tie) {
     __shared__ uint64_t red[4];
     const int q = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const float* d = dist + (int64_t)q * ld;
@@ -204,7 +204,7 @@ void select_chunk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, 
 #pragma unroll
     for (int i = 0; i < SEL_PER_THREAD; ++i) {
         const int64_t r = base + i * 256 + tid;
-        keys[i] = r < n ? dist_key(d[r], (uint32_t)r) : ~0ull;
+        keys[i] = r < n ? dist_key(d[r], tie_of(tie, r)) : ~0ull;
     }
     uint64_t* out = partial + ((int64_t)q * nchunks + chunk) * k;
     uint64_t prev = 0;
@@ -225,7 +225,7 @@ void select_chunk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, 
 
 __global__ __launch_bounds__(256)
 void merge_topk_kernel(const uint64_t* __restrict__ partial, int nchunks, int k,
-                       int32_t* __restrict__ ids, float* __restrict__ out_dist) {
+                       int32_t* __restrict__ ids, float* __restrict__ out_dist, const TieOrder tie) {
     __shared__ uint64_t red[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     const uint64_t* p = partial + (int64_t)q * nchunks * k;
@@ -241,7 +241,7 @@ void merge_topk_kernel(const uint64_t* __restrict__ partial, int nchunks, int k,
         if (tid == 0) {
             const int64_t o = (int64_t)q * k + j;
             if (best == ~0ull) { ids[o] = -1; out_dist[o] = __builtin_inff(); }
-            else { ids[o] = (int32_t)(uint32_t)best; out_dist[o] = key_dist(best); }
+            else { ids[o] = tie_row(tie, (uint32_t)best); out_dist[o] = key_dist(best); }
         }
         prev = best;
         if (best == ~0ull) {

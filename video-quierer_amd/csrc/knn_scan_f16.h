@@ -470,7 +470,8 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
                            const float* __restrict__ queries, int nq, int k,
                            int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
                            int32_t* __restrict__ flags, int layout /*1: scan_f16_top2, 2: scan2_f16_top2, 3: scan3_f16_top2 streams*/,
-                           float eps_rows /* scan_eps_unit(dim) x the largest |row| in the index */) {
+                           float eps_rows /* scan_eps_unit(dim) x the largest |row| in the index */,
+                           const TieOrder tie /* (distance, id) order of the result: vq_common.h */) {
     constexpr int SHARES = 256 / QPW, TPQ = 256 / QPW, POOL = C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;
     __shared__ float kept_v[QPW][SHARES * KEEP];      // kept key values (with packed index bits)
     __shared__ int kept_s[QPW][SHARES * KEEP];        // stream*2 + which (0: 1st key, 1: 2nd key)
@@ -656,11 +657,11 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
         __syncthreads();
         for (int c = share; c < C; c += SHARES) {
             if (cand_row[ql][c] < 0) continue;
-            const uint64_t ki = dist_key(cand_dist[ql][c], (uint32_t)cand_row[ql][c]);
+            const float di = cand_dist[ql][c]; const int ri = cand_row[ql][c];
             int rank = 0;
             for (int j = 0; j < C; ++j)
-                rank += cand_row[ql][j] >= 0 && dist_key(cand_dist[ql][j], (uint32_t)cand_row[ql][j]) < ki;
-            if (rank == kk - 1) dk_s[ql] = cand_dist[ql][c];            // keys are distinct (the row is in the key): one writer
+                rank += cand_row[ql][j] >= 0 && scored_before(tie, cand_dist[ql][j], cand_row[ql][j], di, ri);
+            if (rank == kk - 1) dk_s[ql] = di;                          // rows are distinct: the ranks are a permutation, one writer
         }
         __syncthreads();
     }
@@ -733,7 +734,7 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
                 uint64_t best = ~0ull;
                 for (int i = l16; i < pn; i += TPQ) {
                     if (cand_row[qq][i] < 0) continue;
-                    const uint64_t key = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
+                    const uint64_t key = dist_key(cand_dist[qq][i], tie_of(tie, cand_row[qq][i]));
                     if ((!have_prev || key > prev) && key < best) best = key;
                 }
 #pragma unroll
@@ -744,7 +745,7 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
                 if (l16 == 0) {
                     const size_t o = (size_t)(q0 + qq) * k + j;
                     if (best == ~0ull) { out_ids[o] = -1; out_dist[o] = __builtin_inff(); }
-                    else { out_ids[o] = (int32_t)(uint32_t)best; out_dist[o] = key_dist(best); }
+                    else { out_ids[o] = tie_row(tie, (uint32_t)best); out_dist[o] = key_dist(best); }
                 }
                 prev = best; have_prev = true;
                 if (best == ~0ull) {
@@ -765,10 +766,10 @@ void rescore_verify_kernel_t(const uint32_t* __restrict__ keys, int64_t streams,
             for (int j = valid + l16; j < k; j += TPQ) { out_ids[(size_t)(q0 + qq) * k + j] = -1; out_dist[(size_t)(q0 + qq) * k + j] = __builtin_inff(); }
             for (int i = l16; i < pn; i += TPQ) {
                 if (cand_row[qq][i] < 0) continue;
-                const uint64_t ki = dist_key(cand_dist[qq][i], (uint32_t)cand_row[qq][i]);
+                const float di = cand_dist[qq][i]; const int ri = cand_row[qq][i];
                 int rank = 0;
                 for (int j = 0; j < pn; ++j)
-                    rank += cand_row[qq][j] >= 0 && dist_key(cand_dist[qq][j], (uint32_t)cand_row[qq][j]) < ki;
+                    rank += cand_row[qq][j] >= 0 && scored_before(tie, cand_dist[qq][j], cand_row[qq][j], di, ri);
                 if (rank < k) { out_ids[(size_t)(q0 + qq) * k + rank] = cand_row[qq][i]; out_dist[(size_t)(q0 + qq) * k + rank] = cand_dist[qq][i]; }
             }
         }
@@ -818,7 +819,8 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
                                  int32_t* __restrict__ flags, float eps_rows,
                                  int32_t* __restrict__ slots1 /* with counters1: a ONE-query launch writes the flagged list and */,
-                                 int32_t* __restrict__ counters1 /* the outcome counters itself (collect_flags_kernel's job) */) {
+                                 int32_t* __restrict__ counters1 /* the outcome counters itself (collect_flags_kernel's job) */,
+                                 const TieOrder tie /* (distance, id) order of the result: vq_common.h */) {
     __shared__ __attribute__((aligned(8))) int2 sel[4 * RV_C];      // {key bits, source}: one 8-byte LDS access per entry
     __shared__ float wave_floor[4];
     __shared__ float red[256];
@@ -1038,12 +1040,12 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         // ---- 4. k-th best exact distance among the candidates re-scored so far, by rank counting (all in wave 0) ----
         my_rank = -1;
         if (tid < hi && cand_row[tid] >= 0) {
-            const uint64_t ki = dist_key(cand_dist[tid], (uint32_t)cand_row[tid]);
+            const float di = cand_dist[tid]; const int ri = cand_row[tid];
             int rank = 0;
 #pragma unroll 8
             for (int j = 0; j < hi; ++j)
-                rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
-            if (rank == kk - 1) dk_s = cand_dist[tid];
+                rank += cand_row[j] >= 0 && scored_before(tie, cand_dist[j], cand_row[j], di, ri);
+            if (rank == kk - 1) dk_s = di;
             my_rank = rank;
         }
         if (wave == 0) {
@@ -1123,10 +1125,10 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         __syncthreads();
         for (int i = tid; i < pn; i += 256) {
             if (cand_row[i] < 0) continue;
-            const uint64_t ki = dist_key(cand_dist[i], (uint32_t)cand_row[i]);
+            const float di = cand_dist[i]; const int ri = cand_row[i];
             int rank = 0;
             for (int j = 0; j < pn; ++j)
-                rank += cand_row[j] >= 0 && dist_key(cand_dist[j], (uint32_t)cand_row[j]) < ki;
+                rank += cand_row[j] >= 0 && scored_before(tie, cand_dist[j], cand_row[j], di, ri);
             if (rank < k) { out_ids[(size_t)q * k + rank] = cand_row[i]; out_dist[(size_t)q * k + rank] = cand_dist[i]; }
         }
     }

@@ -71,6 +71,26 @@ __host__ __device__ inline float key_dist(uint64_t k) {
     return __builtin_bit_cast(float, u);
 }
 
+// Tie order.  The reference sorts (distance, id) tuples, so equal distances come back in the order of the CALLER's ids —
+// strings f"{video_id}_{i}" under video_search_system.py:164-166, where "video0_10" < "video0_2".  The device knows rows
+// only; vq_index_set_id_ranks hands it rank[row] = position of the row's id in the caller's id order (and the library keeps
+// the inverse).  Keys then carry the rank where they used to carry the row, every selection stays what it was, and the
+// kernels that emit ids translate back.  Both pointers null = ids ARE the row numbers.
+struct TieOrder {
+    const int32_t* rank;   // [n] rank of row r
+    const int32_t* row;    // [n] row of rank t
+};
+__device__ __forceinline__ uint32_t tie_of(const TieOrder t, int64_t row) { return t.rank ? (uint32_t)t.rank[row] : (uint32_t)row; }
+__device__ __forceinline__ int32_t tie_row(const TieOrder t, uint32_t tie) { return t.row ? t.row[tie] : (int32_t)tie; }
+// (distance, id) order of two scored rows: does (dj, rj) come before (di, ri)?  The ranks are fetched only when the distances
+// are bit-equal and the rows differ — duplicates of a frame; rank-counting loops pay nothing for them otherwise.
+__device__ __forceinline__ bool scored_before(const TieOrder t, float dj, int rj, float di, int ri) {
+    const uint32_t hj = (uint32_t)(dist_key(dj, 0) >> 32), hi = (uint32_t)(dist_key(di, 0) >> 32);
+    if (hj != hi) return hj < hi;
+    if (rj == ri) return false;
+    return t.rank ? t.rank[rj] < t.rank[ri] : rj < ri;
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -37,6 +37,10 @@ struct vq_index {
     uint64_t* d_partial = nullptr; int64_t partial_cap = 0;   // per-chunk top-k keys
     int32_t* d_ids = nullptr; float* d_out = nullptr; int64_t out_cap = 0;
     float* d_upd = nullptr; int64_t upd_cap = 0;      // vq_index_update_rows: staged rows [n][dim] + their row numbers behind them
+    // (distance, id) tie order (vq_index_set_id_ranks): rank of each row's id in the caller's id order + the inverse; rank_n = the
+    // number of rows they cover (0 = none set: ties come back in row order).  A search with rank_n != size is refused.
+    int32_t* d_rank = nullptr; int32_t* d_rank_inv = nullptr; int64_t rank_cap = 0, rank_n = 0;
+    TieOrder tie() const { return rank_n ? TieOrder{d_rank, d_rank_inv} : TieOrder{nullptr, nullptr}; }
     // fp16 scan scratch
     uint16_t* d_q16 = nullptr; int64_t q16_cap = 0;
     uint32_t* d_keys = nullptr; int64_t keys_cap = 0;
@@ -169,9 +173,9 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
         {
             Prof p(x, I_SELECT);
             hipLaunchKernelGGL(select_chunk_kernel, dim3(cur, nchunks), dim3(256), 0, x->stream, x->d_dist, ld, n, k, nchunks,
-                               x->d_partial);
+                               x->d_partial, x->tie());
             hipLaunchKernelGGL(merge_topk_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_partial, nchunks, k,
-                               d_ids + (int64_t)q0 * k, d_dist_out + (int64_t)q0 * k);
+                               d_ids + (int64_t)q0 * k, d_dist_out + (int64_t)q0 * k, x->tie());
         }
     }
     VQ_HIP(hipGetLastError());
@@ -280,8 +284,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 #endif
                     // workgroup -> (row range, query tile) blocking inside an XCD's 32 concurrent workgroups: $VQ_AMD_SCAN_RB = log2 of the
                     // ranges per block (default 2: 4 ranges x 8 query tiles)
-                    static int rb = -1;
-                    if (rb < 0) { const char* e = getenv("VQ_AMD_SCAN_RB"); rb = e ? std::min(5, std::max(0, atoi(e))) : 2; }
+                    static const int rb = [] { const char* e = getenv("VQ_AMD_SCAN_RB"); return e ? std::min(5, std::max(0, atoi(e))) : 2; }();   // (thread-safe: searches of different handles run concurrently)
                     const int rg5 = cdiv(ranges, 1 << rb), qg5 = cdiv(q_tiles, 32 >> rb);
                     hipLaunchKernelGGL(k5, dim3(rg5 * qg5 * 32), dim3(G2_THREADS), SCAN4_LDS_BYTES,
                                        x->stream, x->d_q16, x->rows16, x->dim, n, q_tiles, ranges, rg5, q_pad, x->d_keys, x->dim, rb);
@@ -302,19 +305,19 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             if (large && ver == 3 && !large_qpw4())
                 hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge1_kernel : rescore_verify_large1_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_keys, streams,
                                    q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                                   d_dist_out + q0 * k, x->d_flags + q0, 3, scan_eps_unit(x->dim) * x->row_norm_max);
+                                   d_dist_out + q0 * k, x->d_flags + q0, 3, scan_eps_unit(x->dim) * x->row_norm_max, x->tie());
             else if (large)
                 hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge_kernel : rescore_verify_large_kernel, dim3(cdiv(cur, RVL_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                    q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                                   d_dist_out + q0 * k, x->d_flags + q0, ver == 3 ? 3 : deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
+                                   d_dist_out + q0 * k, x->d_flags + q0, ver == 3 ? 3 : deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max, x->tie());
             else if (ver == 3)
                 hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), (size_t)(RV_C * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
                                    x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
-                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? x->d_counters : nullptr);
+                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? x->d_counters : nullptr, x->tie());
             else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
-                               d_dist_out + q0 * k, x->d_flags + q0, deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max);
+                               d_dist_out + q0 * k, x->d_flags + q0, deep ? 2 : ver, scan_eps_unit(x->dim) * x->row_norm_max, x->tie());
         }
     }
     VQ_HIP(hipGetLastError());
@@ -327,14 +330,14 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     {
         Prof p(x, I_EXACT_DIST);
         hipLaunchKernelGGL(exact_fallback_kernel, dim3(fast_splits, 1), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
-                           d_queries, x->d_slots, x->d_counters, 0, FB_FAST_SLOTS, k, fast_rows, x->d_fb_partial);
+                           d_queries, x->d_slots, x->d_counters, 0, FB_FAST_SLOTS, k, fast_rows, x->d_fb_partial, x->tie());
         hipLaunchKernelGGL(fallback_merge_kernel, dim3(FB_FAST_SLOTS), dim3(256), 0, x->stream, x->d_fb_partial, fast_splits, k, x->d_slots,
-                           x->d_counters, 0, FB_FAST_SLOTS, d_ids, d_dist_out);
+                           x->d_counters, 0, FB_FAST_SLOTS, d_ids, d_dist_out, x->tie());
         for (int64_t base = FB_FAST_SLOTS; base < nq; base += fb_cap) {
             hipLaunchKernelGGL(exact_fallback_kernel, dim3(fb_splits, FB_SLOT_LANES), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
-                               d_queries, x->d_slots, x->d_counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial);
+                               d_queries, x->d_slots, x->d_counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial, x->tie());
             hipLaunchKernelGGL(fallback_merge_kernel, dim3(64), dim3(256), 0, x->stream, x->d_fb_partial, fb_splits, k, x->d_slots,
-                               x->d_counters, (int)base, (int)fb_cap, d_ids, d_dist_out);
+                               x->d_counters, (int)base, (int)fb_cap, d_ids, d_dist_out, x->tie());
         }
     }
     VQ_HIP(hipGetLastError());
@@ -345,6 +348,8 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
 
 int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
     VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
+    VQ_CHECK(x->rank_n == 0 || x->rank_n == x->size, "vq_index_search: the id ranks cover %lld rows, the index holds %lld "
+             "(call vq_index_set_id_ranks again after adding rows, or clear them)", (long long)x->rank_n, (long long)x->size);
     // rows were added un-normalised ON THE DEVICE since the last look (vq_index_add_device: the one add that does not block):
     // is the matrix still near-unit?  This is the only place a search waits for its stream.
     if (mode != 1) VQ_TRY(refresh_norm_range(x));
@@ -404,7 +409,7 @@ int vq_index_destroy(vq_index* x) {
     (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
     (void)hipFree(x->d_counters); (void)hipFree(x->d_fb_partial); (void)hipFree(x->d_upd);
     if (x->h_counters) (void)hipHostFree(x->h_counters);
-    (void)hipFree(x->d_norm_range);
+    (void)hipFree(x->d_norm_range); (void)hipFree(x->d_rank);
     delete x;
     return 0;
 }
@@ -425,6 +430,37 @@ int vq_index_clear(vq_index* x) {
         VQ_HIP(hipStreamSynchronize(x->stream));
     }
     x->norm_dirty = false; x->near_unit = true; x->row_norm_max = 1.0f;
+    x->rank_n = 0;
+    return 0;
+}
+
+int vq_index_set_id_ranks(vq_index* x, const int32_t* rank_of_row, int64_t n) {
+    VQ_TRY(require_init());
+    VQ_CHECK(x && n >= 0 && (n == 0 || rank_of_row), "vq_index_set_id_ranks: bad argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (n == 0) { x->rank_n = 0; return 0; }                     // back to row order
+    VQ_CHECK(n == x->size, "vq_index_set_id_ranks: %lld ranks for an index of %lld rows", (long long)n, (long long)x->size);
+    // a permutation of 0..n-1, checked here: the kernels index two arrays with these values
+    std::vector<int32_t> inv((size_t)n, -1);
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t t = rank_of_row[r];
+        VQ_CHECK(t >= 0 && t < n && inv[(size_t)t] < 0, "vq_index_set_id_ranks: rank_of_row is not a permutation of 0..%lld "
+                 "(row %lld holds %d)", (long long)n - 1, (long long)r, (int)t);
+        inv[(size_t)t] = (int32_t)r;
+    }
+    if (n > x->rank_cap) {
+        VQ_HIP(hipStreamSynchronize(x->stream));                   // a search in flight may still read the old arrays
+        (void)hipFree(x->d_rank); x->d_rank = nullptr; x->d_rank_inv = nullptr; x->rank_cap = 0; x->rank_n = 0;
+        const int64_t cap = round_up(std::max<int64_t>(n, x->cap), 1024);
+        hipError_t e = hipMalloc((void**)&x->d_rank, (size_t)cap * 8);
+        if (e != hipSuccess) return fail(VQ_ERR_OOM, "vq_index_set_id_ranks: hipMalloc failed: %s", hipGetErrorString(e));
+        x->d_rank_inv = x->d_rank + cap;
+        x->rank_cap = cap;
+    }
+    VQ_HIP(hipMemcpyAsync(x->d_rank, rank_of_row, (size_t)n * 4, hipMemcpyHostToDevice, x->stream));
+    VQ_HIP(hipMemcpyAsync(x->d_rank_inv, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, x->stream));
+    VQ_HIP(hipStreamSynchronize(x->stream));                       // `inv` is this frame's, `rank_of_row` the caller's
+    x->rank_n = n;
     return 0;
 }
 
@@ -478,6 +514,9 @@ int vq_index_update_rows(vq_index* x, const float* rows, const int64_t* row_numb
     VQ_TRY(reserve_buf(x->d_upd, x->upd_cap, m * x->dim + m * 2 + 4));
     int64_t* d_rn = (int64_t*)(x->d_upd + round_up(m * x->dim, 2));       // 8-byte aligned behind the rows
     std::vector<int64_t> rn((size_t)m);
+    // `rn` and the caller's `rows` feed asynchronous copies: whichever way this function is left (every VQ_HIP / VQ_TRY below
+    // returns early on error), the stream is drained before `rn` dies (declared after it: destroyed first)
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{x->stream};
     if (m == n) {
         VQ_HIP(hipMemcpyAsync(x->d_upd, rows, (size_t)(n * row_bytes), hipMemcpyHostToDevice, x->stream));
         for (int64_t i = 0; i < m; ++i) rn[(size_t)i] = row_numbers[i];

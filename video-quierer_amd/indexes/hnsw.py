@@ -89,6 +89,9 @@ class HNSWIndex:
         self._ids: List[Hashable] = []            # row -> caller id
         self._row_of: Dict[Hashable, int] = {}    # caller id -> row
         self._identity = True                     # ids are exactly 0..n-1 in row order
+        # (distance, id) tie order on the device (vq_index_set_id_ranks): "stale" until the ranks of the current ids
+        # have been uploaded, "device" afterwards, "host" when the ids cannot be put in one order (see _sync_tie_order)
+        self._tie_order = "device"
         _lib.init(device)
         h = c_void_p()
         _lib.check(_lib.load().vq_index_create(int(dimension), ctypes.byref(h)))
@@ -149,6 +152,54 @@ class HNSWIndex:
                     return np.stack([cls._unit(v) for v in vs])
             return vs / norms[:, None]
 
+    @staticmethod
+    def _ids_are_rows(ids: Sequence[Hashable], base: int) -> bool:
+        """Are `ids` exactly base, base + 1, ... (integers)?  Ids are any hashable: a ragged mix (tuples of different lengths, a
+        str beside a tuple) makes ``np.asarray`` raise — that is simply "no"."""
+        if not ids or not isinstance(ids[0], (int, np.integer)) or not isinstance(ids[-1], (int, np.integer)):
+            return False
+        if isinstance(ids, range):
+            return ids.step == 1 and ids.start == base
+        try:
+            arr = np.asarray(ids)
+        except (ValueError, TypeError):
+            return False
+        return bool(arr.ndim == 1 and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(base, base + len(ids))))
+
+    def _sync_tie_order(self) -> None:
+        """The reference returns ``sorted(candidates)[:k]`` over (distance, id) tuples (hnsw.py:269 / :518): rows at equal
+        distance come back in id order.  The device orders by (distance, rank of the row's id) once it has the ranks
+        (vq_index_set_id_ranks); they are recomputed here, lazily, by the first search after new ids came in.  ``sorted``
+        compares ids only where distances tie, so the reference tolerates ids that have no common order (an int beside a
+        str) as long as no tie meets them; a global ranking cannot — such an index keeps the host-side path (over-fetch,
+        re-sort per query)."""
+        if self._tie_order != "stale":
+            return
+        ids = self._ids
+        n = len(ids)
+        order = None
+        if type(ids[0]) is str and type(ids[-1]) is str and all(type(i) is str for i in ids):
+            try:
+                arr = np.array(ids)                                  # '<U..': numpy compares code points, as str does
+                if arr.dtype.kind == "U" and arr.shape == (n,):
+                    cand = np.argsort(arr, kind="stable")
+                    srt = arr[cand]
+                    if n < 2 or bool(np.all(srt[1:] > srt[:-1])):    # strict: two ids numpy cannot tell apart (trailing NULs) -> Python
+                        order = cand
+            except (ValueError, TypeError):
+                order = None
+        if order is None:
+            try:
+                order = np.fromiter(sorted(range(n), key=ids.__getitem__), dtype=np.int64, count=n)
+            except TypeError:                                        # no total order over these ids
+                _lib.check(_lib.load().vq_index_set_id_ranks(self._h, None, 0))
+                self._tie_order = "host"
+                return
+        rank = np.empty(n, dtype=np.int32)
+        rank[order] = np.arange(n, dtype=np.int32)
+        _lib.check(_lib.load().vq_index_set_id_ranks(self._h, rank.ctypes.data_as(POINTER(c_int32)), n))
+        self._tie_order = "device"
+
     def add(self, vector: np.ndarray, node_id: Hashable) -> None:
         self.add_batch([vector], [node_id])                               # reference :150-229
 
@@ -169,13 +220,13 @@ class HNSWIndex:
             ids_n = node_ids[:n]
             if self._row_of.keys().isdisjoint(ids_n) and len(set(ids_n)) == n:
                 # the ingest case (video_search_system.py:168-176: every frame id is new): no per-id walk
-                _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(unit), n, 0))
                 base = len(self._ids)
+                identity = self._identity and self._ids_are_rows(ids_n, base)     # decided before anything is committed
+                _lib.check(_lib.load().vq_index_add(self._h, _lib.fptr(unit), n, 0))
                 self._row_of.update(zip(ids_n, range(base, base + n)))
-                if self._identity:
-                    arr = np.asarray(ids_n)
-                    if not (arr.ndim == 1 and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(base, base + n))):
-                        self._identity = False
+                self._identity = identity
+                if not identity:
+                    self._tie_order = "stale"
                 self._ids.extend(ids_n)
                 self.element_count += n                                   # reference counts every add (:229)
                 if self.entry_point is None:
@@ -206,6 +257,8 @@ class HNSWIndex:
                     if self._identity and not (isinstance(nid, (int, np.integer)) and int(nid) == base + j):
                         self._identity = False
                 self._ids.extend(fresh_ids)
+                if not self._identity:
+                    self._tie_order = "stale"
             if self.entry_point is None and self._ids:
                 self.entry_point = self._ids[0]
         self.build_time += time.time() - t0
@@ -218,13 +271,13 @@ class HNSWIndex:
         with self.lock:
             if not self._row_of.keys().isdisjoint(node_ids) or len(set(node_ids)) != n:
                 raise ValueError("add_device: ids must be new and unique")
-            _lib.check(_lib.load().vq_index_add_device(self._h, c_void_p(d_rows), n, int(bool(normalize))))
             base = len(self._ids)
+            identity = self._identity and self._ids_are_rows(node_ids, base)
+            _lib.check(_lib.load().vq_index_add_device(self._h, c_void_p(d_rows), n, int(bool(normalize))))
             self._row_of.update(zip(node_ids, range(base, base + n)))       # (a per-id loop here cost 45 ms per 250k rows)
-            if self._identity:
-                arr = np.asarray(node_ids)
-                if not (arr.ndim == 1 and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(base, base + n))):
-                    self._identity = False
+            self._identity = identity
+            if not identity:
+                self._tie_order = "stale"
             self._ids.extend(node_ids)
             self.element_count += n
             if self.entry_point is None and self._ids:
@@ -259,7 +312,15 @@ class HNSWIndex:
             ids, dist = self._raw_search(unit, kk)
             return [[{"id": int(i), "distance": d, "score": np.float32(1.0) - d} for i, d in zip(ri, rd) if i >= 0]
                     for ri, rd in zip(ids, dist)]
-        # arbitrary ids: the library orders ties by row; the reference orders them by id
+        self._sync_tie_order()
+        if self._tie_order == "device":
+            # the caller's ids (strings f"{video_id}_{i}", video_search_system.py:164-166): the device already ordered by
+            # (distance, id rank) — exactly k results fetched, rows mapped to ids, nothing re-sorted
+            ids, dist = self._raw_search(unit, kk)
+            names = self._ids
+            return [[{"id": names[i], "distance": d, "score": np.float32(1.0) - d} for i, d in zip(ri.tolist(), rd) if i >= 0]
+                    for ri, rd in zip(ids, dist)]
+        # ids without a common order: the library orders ties by row; the reference orders them by id
         # (hnsw.py:269/518).  Over-fetch until no tie group is cut at rank k, then re-sort.
         fetch = min(n, kk + 8)
         while True:
@@ -298,8 +359,11 @@ class HNSWIndex:
         return res
 
     def search_device(self, d_queries: int, nq: int, k: int, d_ids: int, d_dist: int, mode: Optional[int] = None) -> None:
-        """Device pointers in/out (unit fp32 queries; int32 row ids; fp32 distances); asynchronous."""
+        """Device pointers in/out (unit fp32 queries; int32 ROW numbers; fp32 distances); asynchronous.  Rows at equal
+        distance come back in the order of their ids (as `search` returns them) unless the ids have no common order."""
         with self.lock:
+            if not self._identity:
+                self._sync_tie_order()
             _lib.check(_lib.load().vq_index_search_device(self._h, c_void_p(d_queries), int(nq), int(k),
                                                           int(self.search_mode if mode is None else mode),
                                                           c_void_p(d_ids), c_void_p(d_dist)))
@@ -366,7 +430,7 @@ class HNSWIndex:
             self.M, self.max_M = s["M"], s["max_M"]
             self.ef_construction, self.ef_search = s["ef_construction"], s["ef_search"]
             self.level_generation_factor = s["level_generation_factor"]
-            self._ids, self._row_of, self._identity = [], {}, True
+            self._ids, self._row_of, self._identity, self._tie_order = [], {}, True, "device"
             ids = list(s["data"].keys())
             if ids:
                 rows = np.ascontiguousarray(np.stack([np.asarray(s["data"][i], dtype=np.float32) for i in ids]))
@@ -376,6 +440,8 @@ class HNSWIndex:
                     if self._identity and not (isinstance(nid, (int, np.integer)) and int(nid) == r):
                         self._identity = False
                 self._ids = ids
+                if not self._identity:
+                    self._tie_order = "stale"
             self.entry_point = s["entry_point"]
             self.element_count = s["element_count"]
 
