@@ -277,6 +277,80 @@ def rehearse_cpu(args):
         dist.destroy_process_group()
 
 
+def world_selfcheck(torch, dist, dev, local, rank, world, comm, stream):
+    """N > 1 only, a few seconds, BEFORE anything is timed: both exchange steps over whichever exchange is up (libvq_amd's
+    own RCCL communicator, or the torch.distributed collectives), checked on every rank against answers recomputed locally —
+    equal / ragged / zero-count all-gathers of rows, and a row-sharded search whose last shard is shorter than k against
+    the same library's search over the unsharded matrix (ids and distances bit-identical).  The first multi-GPU run of this
+    code is the driver's: it validates itself (VERDICT r03 #5; scripts/rccl_two_ranks.py is the stand-alone form)."""
+    from video_quierer_amd.distributed import all_gather_rows, sharded_topk
+    from video_quierer_amd.indexes.hnsw import OptimizedHNSWIndex
+    t0 = time.perf_counter()
+    checks, D = {}, 128
+
+    def rows_of(r, c):                  # rank r's contribution: any rank can regenerate it
+        g = torch.Generator(device=dev)
+        g.manual_seed(4000 + r)
+        return torch.randn((max(c, 1), D), device=dev, generator=g)[:c].contiguous()
+
+    try:
+        cases = (("equal", [64] * world), ("ragged", [5 + 3 * r for r in range(world)]),
+                 ("zero-count", [0 if r == world - 1 else 7 for r in range(world)]))
+        for name, counts in cases:
+            mine = rows_of(rank, counts[rank])
+            want = torch.cat([rows_of(r, c) for r, c in enumerate(counts)])
+            if comm is not None:
+                out = torch.full((sum(counts), D), float("nan"), device=dev)
+                torch.cuda.synchronize(dev)
+                comm.all_gather_rows(mine.data_ptr() if counts[rank] else 0, counts, D, out.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+            else:
+                out = all_gather_rows(mine, counts)
+                torch.cuda.synchronize(dev)
+            checks["all_gather_rows " + name] = bool(out.shape == want.shape and torch.equal(out, want))
+        per, k, nq = 1500, 10, 33
+        n = per * (world - 1) + 7                                   # the last shard holds 7 rows: fewer than k
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321)
+        allrows = torch.randn((n, D), device=dev, generator=g)
+        allrows = (allrows / allrows.norm(dim=1, keepdim=True)).contiguous()
+        q = torch.randn((nq, D), device=dev, generator=g)
+        q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+        lo, hi = rank * per, min(n, (rank + 1) * per)
+        torch.cuda.synchronize(dev)
+        shard, full = OptimizedHNSWIndex(dimension=D, device=local), OptimizedHNSWIndex(dimension=D, device=local)
+        shard.set_stream(stream.cuda_stream)
+        full.set_stream(stream.cuda_stream)
+        mine = allrows[lo:hi].contiguous()
+        torch.cuda.synchronize(dev)
+        shard.add_device(mine.data_ptr(), hi - lo, range(hi - lo), normalize=False)
+        full.add_device(allrows.data_ptr(), n, range(n), normalize=False)
+        ids, dd = torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev)
+        wi, wd = torch.empty_like(ids), torch.empty_like(dd)
+        with torch.cuda.stream(stream):
+            full.search_device(q.data_ptr(), nq, k, wi.data_ptr(), wd.data_ptr())
+            if comm is not None:
+                comm.search_sharded(shard, q.data_ptr(), nq, k, lo, ids.data_ptr(), dd.data_ptr())
+            else:
+                shard.search_device(q.data_ptr(), nq, k, ids.data_ptr(), dd.data_ptr())
+                ids, dd = sharded_topk(ids, dd, lo, k)
+        stream.synchronize()
+        torch.cuda.synchronize(dev)
+        if comm is not None:
+            comm.check()
+        checks["sharded search (last shard shorter than k) == unsharded search"] = bool(torch.equal(ids, wi) and torch.equal(dd, wd))
+        shard.close()
+        full.close()
+    except Exception as e:               # noqa: BLE001 - a rank that cannot run a check still reaches the agreement below
+        checks["exception"] = False
+        checks["exception_text"] = f"{type(e).__name__}: {e}"[:300]
+    mine_ok = all(v for v in checks.values() if isinstance(v, bool))
+    ok = torch.tensor([1 if mine_ok else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return {"ok": bool(int(ok.item())), "this_rank_ok": mine_ok, "seconds": time.perf_counter() - t0, "checks": checks,
+            "exchange": "libvq_amd vq_comm_* (RCCL)" if comm is not None else "torch.distributed"}
+
+
 def run_config4(args, torch, dist, dev, local, rank, world, comm, exchange, backend, cfg, encs, streams, fence, max_over_ranks):
     """configs[3]: 4 videos x 1000 frames, video v on ranks {2v, 2v+1} at N = 8 (contiguous frame shards at any N) ->
     encode the shard -> all-gather of the per-shard embeddings (ragged counts; vq_allgather_rows over RCCL when the native
@@ -498,6 +572,22 @@ def main():
         fence()
         done.set()
 
+    selfcheck = None
+    if world > 1:
+        box = {}
+        if comm is not None:
+            first_native_call("exchange self-check", lambda: box.update(r=world_selfcheck(torch, dist, dev, local, rank, world, comm, stream)))
+        else:
+            box["r"] = world_selfcheck(torch, dist, dev, local, rank, world, comm, stream)
+        selfcheck = box["r"]
+        if not selfcheck["ok"] and comm is not None:
+            # the native exchange gives wrong answers on some rank: every rank knows (all_reduce above) and leaves the same way
+            # as after a failed bring-up; the supervisors relaunch with the torch.distributed exchange
+            sys.stderr.write(f"bench.py[rank {rank}]: the native exchange failed its self-check: {selfcheck['checks']}\n")
+            sys.stderr.flush()
+            comm.close()
+            dist.destroy_process_group()
+            sys.exit(RELAUNCH_CODE)
     first_native_call("all-gather of embeddings", lambda: step(0))
     for i in range(args.warmup):
         step(i)
@@ -554,7 +644,7 @@ def main():
                    "timed_frames": world * args.steps * BATCH,
                    "parallelism": f"dp{world} (frame shards; all-gather of embeddings per step)" if world > 1 else "single GPU"},
         "world": {"size": world, "backend": ("nccl = RCCL %s" % ".".join(map(str, torch.cuda.nccl.version()))) if world > 1 and backend == "nccl" else backend if world > 1 else None,
-                  "exchange": exchange, "ranks": ranks_info},
+                  "exchange": exchange, "ranks": ranks_info, "selfcheck": selfcheck},
         "sustained": sustained,
         "sustained_frames_per_s": sustained["frames_per_s"] if sustained else None,
         "encode_mfma_frac_whole_pass": frames_per_s / world * flop_per_frame / PEAK_BF16,

@@ -249,13 +249,30 @@ int vq_comm_unique_id(void* out_id, int bytes);
 int vq_comm_init(int rank, int world, const void* unique_id, vq_comm** out);
 int vq_comm_destroy(vq_comm* comm);
 int vq_comm_info(vq_comm* comm, int* rank, int* world, int* rccl_version);
+/* Collectives and failures.  Every rank must make the same sequence of calls with the same counts / nq / k.  No call leaves a
+ * rank waiting in a collective its peer never enters: argument checks that fail alike on every rank come first; a call
+ * that needs more scratch than the ranks have agreed on allocates and then exchanges ONE status word per rank (an
+ * allocation that failed anywhere makes every rank return an error before the data collective; steady-state calls skip
+ * this); a failure that can strike one rank only after that point is carried INTO the collective as a status word (below). */
 /* counts[world]: rows each rank contributes (this rank's d_local holds counts[rank] x dim fp32); d_out receives
- * sum(counts) x dim in rank (= frame) order on every rank.  Asynchronous on hip_stream. */
+ * sum(counts) x dim in rank (= frame) order on every rank.  Asynchronous on hip_stream, except for the call that first
+ * needs (more) padding scratch for ragged counts: that one waits for the stream once (status exchange). */
 int vq_allgather_rows(vq_comm* comm, const void* d_local, const int64_t* counts, int dim, void* d_out, void* hip_stream);
+/* The ragged all-gather's second half on its own: d_padded [world][pad_rows][dim] fp32 -> the first counts[r] rows of every
+ * rank's block, back to back, at d_out.  Asynchronous on hip_stream. */
+int vq_compact_gathered_rows(const void* d_padded, const int64_t* counts, int world, int64_t pad_rows, int dim, void* d_out,
+                             void* hip_stream);
 /* This rank's index holds rows [row_offset, row_offset + size) of the global matrix.  Same modes and result
- * layout as vq_index_search_device, ids are GLOBAL row numbers, identical on every rank.  world*k <= 1024. */
+ * layout as vq_index_search_device, ids are GLOBAL row numbers, identical on every rank.  world*k <= 1024.
+ * A rank whose LOCAL scan fails (its shard refuses the requested mode, stale id ranks, a launch error, a row_offset its
+ * shard overflows) returns that error — after entering the exchange with empty keys and a non-zero status word.  On its
+ * peers the call itself returns 0 (it is asynchronous), every result slot comes back empty (id -1, +inf) and
+ * vq_comm_check reports the failed rank once the stream has been synchronised.  Ties across shards are ordered by global
+ * row number (vq_index_set_id_ranks orders ties inside a shard only). */
 int vq_index_search_sharded(vq_index* idx, vq_comm* comm, const void* d_queries_f32, int nq, int k, int mode,
                             int64_t row_offset, void* d_ids_i32, void* d_dist_f32);
+/* 0, or VQ_ERR_STATE once after a sharded search on this communicator was voided by a peer's local failure. */
+int vq_comm_check(vq_comm* comm);
 /* The merge step alone: [world][nq][k] shard results with global ids (-1 / +inf = empty slot) -> [nq][k]. */
 int vq_merge_topk_device(const void* d_all_ids_i32, const void* d_all_dist_f32, int world, int nq, int k,
                          void* d_ids_i32, void* d_dist_f32, void* hip_stream);

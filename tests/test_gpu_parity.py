@@ -1023,6 +1023,70 @@ def test_native_comm_world_of_one_over_rccl(gpu_lib):
     idx.synchronize()
     oid, od = knn_oracle.topk(idx._export(), qs, 10)
     assert np.array_equal(ids.cpu().numpy(), oid + 1_000_000) and np.array_equal(dd.cpu().numpy(), od)
+    comm.check()                                                           # nothing was voided
+
+    # ---- a rank whose LOCAL scan fails still enters the exchange: here the shard refuses the fp16 mode
+    # (rows stored un-normalised at 3x unit length).  The failing rank gets its error, the merge sees its status word:
+    # every list comes back empty and the communicator is flagged — then it keeps working.
+    from video_quierer_amd.indexes.hnsw import MODE_FP16, OptimizedHNSWIndex
+    bad = OptimizedHNSWIndex(dimension=512)
+    big = np.ascontiguousarray(rows[:2000] * np.float32(3.0))
+    gpu_lib.check(gpu_lib.load().vq_index_add(bad._h, gpu_lib.fptr(big), 2000, 0))
+    bad._ids = list(range(2000)); bad.element_count = 2000; bad.entry_point = 0
+    ids.fill_(7); dd.fill_(7.0)
+    with pytest.raises(ValueError, match="fp16 scan needs"):
+        comm.search_sharded(bad, q_t.data_ptr(), 33, 10, 0, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
+    bad.synchronize()
+    assert bool((ids == -1).all()) and bool(torch.isinf(dd).all())        # visibly empty, not silently partial
+    with pytest.raises(gpu_lib.VqError, match="voided.*rank 0"):
+        comm.check()
+    comm.check()                                                           # reported once
+    comm.search_sharded(idx, q_t.data_ptr(), 33, 10, 0, ids.data_ptr(), dd.data_ptr())
+    idx.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(dd.cpu().numpy(), od)
+    comm.check()
+    bad.close()
+
+    # ---- the ragged all-gather's compaction on a synthetic padded buffer (counts differ only BETWEEN ranks, so one rank never
+    # reaches it through vq_allgather_rows): 4 "ranks", 9 rows of padding each, counts 9 / 0 / 4 / 1
+    from ctypes import c_int64, c_void_p
+    counts = [9, 0, 4, 1]
+    padded = torch.from_numpy(rng.standard_normal((4, 9, 512)).astype(np.float32)).cuda()
+    outc = torch.full((sum(counts), 512), float("nan"), device="cuda")
+    gpu_lib.check(gpu_lib.load().vq_compact_gathered_rows(c_void_p(padded.data_ptr()), (c_int64 * 4)(*counts), 4, 9, 512,
+                                                          c_void_p(outc.data_ptr()), c_void_p(st)))
+    torch.cuda.synchronize()
+    assert torch.equal(outc, torch.cat([padded[r, :c] for r, c in enumerate(counts)]))
+    assert gpu_lib.load().vq_compact_gathered_rows(c_void_p(padded.data_ptr()), (c_int64 * 4)(9, 10, 0, 0), 4, 9, 512,
+                                                   c_void_p(outc.data_ptr()), c_void_p(st)) < 0             # a count above the padding
+    idx.close()
+    comm.close()
+
+
+@pytest.mark.timeout(180)
+def test_native_comm_scratch_allocation_failure_is_agreed_before_the_collective(gpu_lib, monkeypatch):
+    """A call that outgrows the exchange scratch allocates and then exchanges one status word per rank (agree()): with an
+    allocation failure injected ($VQ_COMM_FAIL_ALLOC) the call returns an error BEFORE the data collective — on a real
+    node every rank would, instead of the healthy ranks waiting in ncclAllGather for the one that left — and the next call
+    (allocation succeeds) runs normally."""
+    from video_quierer_amd.comm import Comm
+    monkeypatch.setenv("VQ_COMM_FAIL_ALLOC", "1")
+    comm = Comm.single()
+    monkeypatch.delenv("VQ_COMM_FAIL_ALLOC")
+    rng = np.random.default_rng(6)
+    rows = knn_oracle.normalize_rows(rng.standard_normal((3000, 128)).astype(np.float32))
+    qs = knn_oracle.normalize_rows(rng.standard_normal((5, 128)).astype(np.float32))
+    idx = _mk_index(rows)
+    q_t = torch.from_numpy(qs).cuda()
+    ids = torch.empty((5, 4), dtype=torch.int32, device="cuda")
+    dd = torch.empty((5, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(gpu_lib.VqError, match="scratch hipMalloc"):
+        comm.search_sharded(idx, q_t.data_ptr(), 5, 4, 0, ids.data_ptr(), dd.data_ptr())
+    comm.search_sharded(idx, q_t.data_ptr(), 5, 4, 0, ids.data_ptr(), dd.data_ptr())
+    idx.synchronize()
+    oid, od = knn_oracle.topk(idx._export(), qs, 4)
+    assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(dd.cpu().numpy(), od)
+    comm.check()
     idx.close()
     comm.close()
 

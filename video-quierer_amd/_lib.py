@@ -130,6 +130,8 @@ SIGNATURES = {
     "vq_comm_destroy": (c_int, [c_void_p]),
     "vq_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vq_allgather_rows": (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_int, c_void_p, c_void_p]),
+    "vq_compact_gathered_rows": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "vq_comm_check": (c_int, [c_void_p]),
     "vq_index_search_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "vq_merge_topk_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vq_frame_quality_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),

@@ -76,11 +76,18 @@ class Comm:
     def search_sharded(self, index, d_queries: int, nq: int, k: int, row_offset: int, d_ids: int, d_dist: int,
                        mode: Optional[int] = None) -> None:
         """``index`` (an ``indexes.hnsw.HNSWIndex``) holds rows ``[row_offset, row_offset + size)`` of the global
-        matrix; the exact global top-k (global row ids) lands at ``d_ids`` / ``d_dist`` on every rank."""
+        matrix; the exact global top-k (global row ids) lands at ``d_ids`` / ``d_dist`` on every rank.  A rank whose own
+        scan fails raises here (after entering the exchange, so its peers do not hang); the peers get empty lists and
+        ``check()`` raises on them."""
         with index.lock:
             _lib.check(_lib.load().vq_index_search_sharded(index._h, self._h, c_void_p(d_queries), int(nq), int(k),
                                                            int(index.search_mode if mode is None else mode),
                                                            int(row_offset), c_void_p(d_ids), c_void_p(d_dist)))
+
+    def check(self) -> None:
+        """Raises once if a sharded search on this communicator was voided by a PEER's local failure (the failing rank got
+        its own exception from ``search_sharded``; here the call returned empty lists).  Call after synchronising."""
+        _lib.check(_lib.load().vq_comm_check(self._h))
 
     def close(self) -> None:
         if getattr(self, "_h", None):

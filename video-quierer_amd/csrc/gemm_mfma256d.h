@@ -38,6 +38,23 @@
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
 
+// Cache policy of the LDS-DMA operand loads (the `aux` immediate of buffer_load ... lds: 0 = default, 2 = nt "streamed, first
+// to leave L2").  In the multi-tile kernel a workgroup walks `tpw` column tiles of one tile row: its A panel is read again for
+// every column tile while each W panel passes through an XCD's L2 once — W marked nt keeps the A panels resident
+// (DESIGN.md section 4 "Round 4").  Build-time switches so that variants can be A/B-ed as separate libraries ($VQ_AMD_LIB).
+#ifndef VQ_GEMM_DM_W_AUX
+#define VQ_GEMM_DM_W_AUX 0
+#endif
+#ifndef VQ_GEMM_DM_A_AUX
+#define VQ_GEMM_DM_A_AUX 0
+#endif
+#ifndef VQ_GEMM_D_W_AUX
+#define VQ_GEMM_D_W_AUX 0
+#endif
+#ifndef VQ_GEMM_D_A_AUX
+#define VQ_GEMM_D_A_AUX 0
+#endif
+
 namespace vq {
 
 #ifdef VQ_GEMM_TOWER_STAMPS      // `make STAMPS=1`: diagnostic build for scripts/gemm_tower_stamps.py, never the product library
@@ -113,8 +130,8 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         char* base = smem + buf * G2_BUF;
         const int koff = kt * G2_BK;
         if constexpr (BUF) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][0]), 16, a_voff[hm][0], koff * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][1]), 16, a_voff[hm][1], koff * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][0]), 16, a_voff[hm][0], koff * 2, 0, VQ_GEMM_D_A_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + a_dst[hm][1]), 16, a_voff[hm][1], koff * 2, 0, VQ_GEMM_D_A_AUX);
         } else {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][0] + koff), (lds_void_t*)(base + a_dst[hm][0]), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[hm][1] + koff), (lds_void_t*)(base + a_dst[hm][1]), 16, 0, 0);
@@ -124,8 +141,8 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         char* base = smem + buf * G2_BUF;
         const int koff = kt * G2_BK;
         if constexpr (BUF) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][0]), 16, w_voff[hn][0], koff * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][1]), 16, w_voff[hn][1], koff * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][0]), 16, w_voff[hn][0], koff * 2, 0, VQ_GEMM_D_W_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][1]), 16, w_voff[hn][1], koff * 2, 0, VQ_GEMM_D_W_AUX);
         } else {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][1] + koff), (lds_void_t*)(base + w_dst[hn][1]), 16, 0, 0);
@@ -338,14 +355,14 @@ void gemm_tn256dm_kernel(const uint16_t* __restrict__ A, int lda,
     auto stage_a = [&](int buf, int hm, int kt) __attribute__((always_inline)) {
         char* base = smem + buf * G2_BUF + a_dst0 + hm * (64 * 128);
         const int soff = __builtin_amdgcn_readfirstlane(kt * (G2_BK * 2) + hm * 8 * a_row8);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base), 16, a_v0, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + 1024), 16, a_v1, soff + a_row8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base), 16, a_v0, soff, 0, VQ_GEMM_DM_A_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_void_t*)(base + 1024), 16, a_v1, soff + a_row8, 0, VQ_GEMM_DM_A_AUX);
     };
     auto stage_w_at = [&](int buf, int hn, int kt, int wt) __attribute__((always_inline)) {
         char* base = smem + buf * G2_BUF + w_dst0 + hn * (32 * 128);
         const int soff = __builtin_amdgcn_readfirstlane(wt + kt * (G2_BK * 2) + hn * 4 * w_row8);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + w_row8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base), 16, w_v0, soff, 0, VQ_GEMM_DM_W_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + 1024), 16, w_v1, soff + w_row8, 0, VQ_GEMM_DM_W_AUX);
     };
     auto stage_w = [&](int buf, int hn, int kt) __attribute__((always_inline)) { stage_w_at(buf, hn, kt, w_tile); };
 

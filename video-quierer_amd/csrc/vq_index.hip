@@ -366,6 +366,10 @@ int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode
 // vq_comm.hip: this rank's part of a row-sharded search, on the index's stream (returned so that the exchange is
 // enqueued behind it).
 namespace vq {
+hipStream_t index_stream(vq_index* x) {
+    std::lock_guard<std::mutex> lk(x->mu);
+    return x->stream;
+}
 int index_search_local(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist,
                        hipStream_t* stream_out, int64_t* size_out) {
     std::lock_guard<std::mutex> lk(x->mu);
