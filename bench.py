@@ -847,9 +847,18 @@ def main():
                 same = idx.search_batch(list(q[:64].cpu().numpy()), 20)
                 hs["string_and_int_lists_agree"] = bool(all([int(r_["id"].split("_")[0][5:]) * per_video + int(r_["id"].split("_")[1]) for r_ in a] == [r_["id"] for r_ in b]
                                                             for a, b in zip(rb, same)))
-                lat["q1_host_sync"] = hs
                 sidx.close()
                 del sidx
+                # ... and on an index of the size the caller's own videos give (configs[3]: 4 x 1000 frames): the exact scan's
+                # two-launch form for a handful of queries (exact_dist_small_kernel + select_small_kernel)
+                small = OptimizedHNSWIndex(dimension=dimq, device=local)
+                blk = torch.randn((4000, dimq), dtype=torch.float32, device=dev, generator=g2s)
+                torch.cuda.synchronize(dev)
+                small.add_device(blk.data_ptr(), 4000, [f"video{r // 1000}_{r % 1000}" for r in range(4000)], normalize=True)
+                small.synchronize()
+                hs["string_ids_4000_rows"] = host_sync_latency(small, 20)
+                small.close()
+                lat["q1_host_sync"] = hs
             except Exception as e:                                       # never lose the line over a secondary leg
                 lat["q1_host_sync"] = {"error": repr(e)}
         # CPU work of the search leg (rank 0): deferred until every GPU leg has run, so the GPU legs are contiguous on the box's

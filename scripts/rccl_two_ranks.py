@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The native exchange (vq_comm_*) with world = 2: equal and ragged all-gathers (a 0-count rank too) and the sharded search
-with a shard shorter than k, against the single-index oracle answer.  Rank r takes GPU r when the box has two; on a ONE-GPU
+with a shard shorter than k, against the single-index oracle answer; then the two failure paths (a local scan that fails on one
+rank, a scratch allocation that fails on one rank): both ranks return an error, nobody hangs, the next call is exact.  Rank r takes GPU r when the box has two; on a ONE-GPU
 box both ranks land on device 0 and RCCL refuses ('Duplicate GPU detected', measured on this pool: exit code 3) — so this is
 the check to run first on a multi-GPU node, before bench.py --gpus N.
     python scripts/rccl_two_ranks.py            (starts its own two ranks)"""
@@ -75,5 +76,44 @@ idx.synchronize()
 oid, od = knn_oracle.topk(rows, qs, 10)
 assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(dd.cpu().numpy(), od), rank
 print(f"rank {rank}: sharded search over two ranks == the single-index oracle answer (ids and distances bit-exact)", flush=True)
+comm.check()
+# a rank whose LOCAL scan fails still enters the exchange: rank 1's shard refuses the fp16 mode (rows stored at 3x unit length).
+# Rank 1 gets its error; rank 0's call returns, its lists are empty and comm.check() names rank 1.  Nobody hangs.
+from video_quierer_amd.indexes.hnsw import MODE_FP16
+bad = OptimizedHNSWIndex(dimension=D, device=DEV)
+big = np.ascontiguousarray(rows[:2000] * np.float32(3.0 if rank == 1 else 1.0))
+_lib.check(_lib.load().vq_index_add(bad._h, _lib.fptr(big), 2000, 0))
+bad._ids = list(range(2000)); bad.element_count = 2000; bad.entry_point = 0
+ids.fill_(7)
+try:
+    comm.search_sharded(bad, q_t.data_ptr(), 33, 10, 2000 * rank, ids.data_ptr(), dd.data_ptr(), mode=MODE_FP16)
+    raised = False
+except ValueError as e:
+    raised = "fp16 scan needs" in str(e)
+bad.synchronize()
+assert raised == (rank == 1), (rank, raised)
+assert bool((ids == -1).all()), rank
+try:
+    comm.check(); flagged = False
+except _lib.VqError as e:
+    flagged = "rank 1" in str(e)
+assert flagged, rank
+print(f"rank {rank}: a failed local scan on rank 1 voided the call on both ranks without a hang", flush=True)
+bad.close()
+# an allocation that fails on ONE rank is agreed on before the data collective: both ranks return an error, the next call works
+os.environ["VQ_COMM_FAIL_ALLOC"] = "1" if rank == 1 else "0"
+comm2 = Comm.from_torch_distributed(DEV)
+del os.environ["VQ_COMM_FAIL_ALLOC"]
+try:
+    comm2.search_sharded(idx, q_t.data_ptr(), 33, 10, lo, ids.data_ptr(), dd.data_ptr())
+    failed = False
+except _lib.VqError as e:
+    failed = ("scratch hipMalloc" in str(e)) if rank == 1 else ("rank 1 could not prepare" in str(e))
+assert failed, rank
+comm2.search_sharded(idx, q_t.data_ptr(), 33, 10, lo, ids.data_ptr(), dd.data_ptr())
+idx.synchronize()
+assert np.array_equal(ids.cpu().numpy(), oid) and np.array_equal(dd.cpu().numpy(), od), rank
+print(f"rank {rank}: a scratch allocation failing on rank 1 made both ranks return before the collective; the retry is exact", flush=True)
+comm2.close()
 idx.close(); comm.close()
 dist.barrier(); dist.destroy_process_group()

@@ -193,6 +193,175 @@ __device__ __forceinline__ uint64_t block_min_u64(uint64_t v, uint64_t* red /*[4
     return b;
 }
 
+// ---- exact distances for a HANDFUL of queries (the reference caller's one `index.search(query, k*2)` at a time,
+// video_search_system.py:297, on an index of a few thousand frames) ----
+// exact_dist_kernel above is shaped for batches (32 queries per tile, scalar loads, a load -> barrier -> multiply -> barrier
+// round trip per 64-dim panel): 49 us for ONE query over 4,000 rows, nearly all of it exposed memory latency.  Here: 64 rows x
+// up to 8 queries per workgroup, the row panel fetched as 16-byte loads one panel AHEAD of the multiply (registers), the
+// queries converted to fp64 once.  Thread (r = tid & 63, g = tid >> 6) owns row r and queries 2g, 2g + 1; the chain is the
+// same index-order fp64 sum (one rounding to fp32 at the end), so the distances are the same bits.
+constexpr int EDS_MAX_Q = 8;
+__global__ __launch_bounds__(256)
+void exact_dist_small_kernel(const float* __restrict__ rows, int64_t n, int dim,
+                             const float* __restrict__ queries, int nq,
+                             float* __restrict__ dist /*[nq][ld]*/, int64_t ld) {
+    __shared__ float xs[2][64][65];
+    extern __shared__ __attribute__((aligned(16))) double qd[];        // [EDS_MAX_Q][dim]
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int panels = (dim + 63) >> 6;
+    // a thread fetches four 16-byte pieces of a 64 x 64 panel: piece p = tid + 256 u -> row p >> 4, floats (p & 15) * 4 ..+3
+    float4 nx[4];
+    auto fetch = [&](int pi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = tid + 256 * u, rr = p >> 4, c4 = (p & 15) * 4;
+            const int64_t gr = row0 + rr;
+            const int c = pi * 64 + c4;
+            nx[u] = float4{0.f, 0.f, 0.f, 0.f};
+            if (gr < n && c < dim) nx[u] = *(const float4*)(rows + gr * dim + c);        // dim % 4 == 0 (vq_index_create)
+        }
+    };
+    fetch(0);
+    for (int i = tid; i < EDS_MAX_Q * dim; i += 256) {
+        const int q = i / dim;
+        qd[i] = q < nq ? (double)queries[i] : 0.0;
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    const bool live0 = 2 * g < nq, live1 = 2 * g + 1 < nq;
+    for (int pi = 0; pi < panels; ++pi) {
+        float (*x)[65] = xs[pi & 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = tid + 256 * u, rr = p >> 4, c4 = (p & 15) * 4;
+            x[rr][c4] = nx[u].x; x[rr][c4 + 1] = nx[u].y; x[rr][c4 + 2] = nx[u].z; x[rr][c4 + 3] = nx[u].w;
+        }
+        __syncthreads();                               // (two buffers: the next panel's stores cannot overtake this panel's reads)
+        if (pi + 1 < panels) fetch(pi + 1);
+        if (live0) {                                   // wave-uniform: a wave shares g
+            const double* q0 = qd + (size_t)(2 * g) * dim + pi * 64;
+            const double* q1 = q0 + dim;
+            const int lim = min(64, dim - pi * 64);
+            if (live1) {
+                for (int c = 0; c < lim; ++c) { const double xv = (double)x[r][c]; acc0 += xv * q0[c]; acc1 += xv * q1[c]; }
+            } else {
+                for (int c = 0; c < lim; ++c) acc0 += (double)x[r][c] * q0[c];
+            }
+        }
+    }
+    const int64_t gr = row0 + r;
+    if (gr < n) {
+        if (live0) dist[(int64_t)(2 * g) * ld + gr] = 1.0f - (float)acc0;
+        if (live1) dist[(int64_t)(2 * g + 1) * ld + gr] = 1.0f - (float)acc1;
+    }
+}
+
+// ---- exact selection for the same case: ONE workgroup per query finds the k smallest (distance, tie) keys of n distances ----
+// select_chunk_kernel + merge_topk_kernel extract the minimum k times (two barriers per round: 26 us at k = 10, 43 us at
+// k = 20, whatever n).  Here: (1) every thread's smallest key; (2) T = the k-th smallest of the 256 thread minima — at least
+// k keys are <= T, so the k smallest overall are; (3) the keys <= T (k of them plus a few) are collected and (4) ranked by
+// counting.  More collected keys than the list holds (a pathological layout) -> the workgroup falls back to extracting
+// minima from global memory.  n <= SEL_SMALL_MAX_N.
+constexpr int SEL_SMALL_MAX_N = 32768;
+constexpr int SEL_SMALL_LIST = 1024;
+__global__ __launch_bounds__(256)
+void select_small_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k,
+                         int32_t* __restrict__ ids, float* __restrict__ out_dist, const TieOrder tie) {
+    __shared__ uint64_t mins[256];
+    __shared__ uint64_t list[SEL_SMALL_LIST];
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t thr_s;
+    __shared__ int cnt_s;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* d = dist + (int64_t)q * ld;
+    int32_t* oi = ids + (int64_t)q * k;
+    float* od = out_dist + (int64_t)q * k;
+    // Both passes walk the distances as 16-byte pieces, four pieces per thread in flight (a one-element-per-iteration loop paid a
+    // dependent L2 round trip per element: 17 us at 4,000 rows, 35 us at 16,000).  Piece p holds rows 4p .. 4p + 3.
+    const int64_t pieces = (n + 3) >> 2;
+    const bool vec = (ld & 3) == 0;                                   // rows of `dist` 16-byte aligned (ld is a multiple of 64)
+    auto keys_of = [&](int64_t p, uint64_t (&key)[4]) __attribute__((always_inline)) {
+        const int64_t r0 = p * 4;
+        float v[4]; uint32_t t[4];
+        if (vec && r0 + 3 < n) {
+            const float4 f = *(const float4*)(d + r0);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            if (tie.rank) { const int4 tt = *(const int4*)(tie.rank + r0); t[0] = tt.x; t[1] = tt.y; t[2] = tt.z; t[3] = tt.w; }
+            else { t[0] = (uint32_t)r0; t[1] = (uint32_t)r0 + 1; t[2] = (uint32_t)r0 + 2; t[3] = (uint32_t)r0 + 3; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) key[e] = dist_key(v[e], t[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) key[e] = (p < pieces && r0 + e < n) ? dist_key(d[r0 + e], tie_of(tie, r0 + e)) : ~0ull;
+        }
+    };
+    uint64_t mine = ~0ull;
+    for (int64_t p0 = tid; p0 < pieces; p0 += 4 * 256) {
+        uint64_t key[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + 256 * u;
+            if (p < pieces) keys_of(p, key[u]);
+            else { key[u][0] = key[u][1] = key[u][2] = key[u][3] = ~0ull; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine = key[u][e] < mine ? key[u][e] : mine;
+    }
+    mins[tid] = mine;
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    const int kk = (int)min((int64_t)k, n);                      // results that exist
+    {
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) { const uint64_t o = mins[j]; rank += (o < mine) || (o == mine && j < tid); }
+        if (rank == min(kk, 256) - 1) thr_s = mine;              // ranks are a permutation: one writer
+    }
+    __syncthreads();
+    const uint64_t thr = kk > 256 ? ~0ull - 1 : thr_s;           // k beyond the thread count: every real key competes
+    for (int64_t p0 = tid; p0 < pieces; p0 += 4 * 256) {
+        uint64_t key[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + 256 * u;
+            if (p < pieces) keys_of(p, key[u]);
+            else { key[u][0] = key[u][1] = key[u][2] = key[u][3] = ~0ull; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (key[u][e] <= thr) {
+                    const int pos = atomicAdd(&cnt_s, 1);
+                    if (pos < SEL_SMALL_LIST) list[pos] = key[u][e];
+                }
+    }
+    __syncthreads();
+    const int c = cnt_s;
+    for (int j = kk + tid; j < k; j += 256) { oi[j] = -1; od[j] = __builtin_inff(); }
+    if (c <= SEL_SMALL_LIST) {
+        for (int i = tid; i < c; i += 256) {
+            const uint64_t ki = list[i];
+            int rank = 0;
+            for (int j = 0; j < c; ++j) rank += list[j] < ki;    // keys are distinct (the tie word is a permutation of the rows)
+            if (rank < kk) { oi[rank] = tie_row(tie, (uint32_t)ki); od[rank] = key_dist(ki); }
+        }
+        return;
+    }
+    uint64_t prev = 0;                                           // the slow way, from global memory: kk rounds of "smallest key above the previous"
+    for (int j = 0; j < kk; ++j) {
+        uint64_t best = ~0ull;
+        for (int64_t r = tid; r < n; r += 256) {
+            const uint64_t key = dist_key(d[r], tie_of(tie, r));
+            if ((j == 0 || key > prev) && key < best) best = key;
+        }
+        best = block_min_u64(best, red, tid);
+        if (tid == 0) { oi[j] = tie_row(tie, (uint32_t)best); od[j] = key_dist(best); }
+        prev = best;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void select_chunk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k, int nchunks,
                          uint64_t* __restrict__ partial /*[q][nchunks][k]*/, const TieOrder tie) {

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -50,6 +51,12 @@ struct vq_index {
     int32_t* d_slots = nullptr; int64_t slots_cap = 0;
     int32_t* d_counters = nullptr; int32_t* h_counters = nullptr;
     uint64_t* d_fb_partial = nullptr; int64_t fbp_cap = 0;
+    int32_t* d_counters_host = nullptr;   // the device's address of h_counters (pinned + mapped): a host-synchronous search lets its kernels write the counters there
+    // vq_index_search (host arrays in and out, the reference caller's call): pinned staging for the queries, and a pinned + MAPPED
+    // result buffer the kernels write straight into — no device-to-host copy command on the one-query path
+    float* h_q = nullptr; int64_t hq_cap = 0;
+    char* h_res = nullptr; char* d_res = nullptr; int64_t hres_cap = 0;
+    bool fb_deferred = false;      // a host-synchronous fp16 search left its fallback launches to the host (after it has read the flagged count)
     bool stats_pending = false;    // the last search's counters are still on their way to h_counters
     int64_t stats[3] = {0, 0, 0};
     // |row|^2 range of rows added without normalisation (device: min/max fp32 bits); read back lazily by the first
@@ -161,6 +168,29 @@ int search_exact(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_
     const int64_t budget = (int64_t)128 << 20;                 // 512 MiB of fp32 distances per slice
     int qslice = (int)std::max<int64_t>(32, std::min<int64_t>(nq, budget / ld) / 32 * 32);
     VQ_TRY(reserve_buf(x->d_dist, x->dist_cap, (int64_t)std::min(qslice, (int)round_up(nq, 32)) * ld));
+    if (nq <= EDS_MAX_Q && n <= SEL_SMALL_MAX_N && x->dim % 4 == 0 && (size_t)EDS_MAX_Q * x->dim * 8 <= (size_t)96 << 10) {
+        // a handful of queries over a small index — the reference caller's one search at a time over a few thousand frames:
+        // two short launches (knn_kernels.h)
+        const size_t qbytes = (size_t)EDS_MAX_Q * x->dim * 8;
+        static std::atomic<size_t> attr_bytes{0};
+        if (qbytes > attr_bytes) {
+            VQ_HIP(hipFuncSetAttribute((const void*)exact_dist_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qbytes));
+            attr_bytes = qbytes;
+        }
+        {
+            Prof p(x, I_EXACT_DIST);
+            hipLaunchKernelGGL(exact_dist_small_kernel, dim3(cdiv(n, 64)), dim3(256), qbytes, x->stream, x->rows, n, x->dim, d_queries, nq,
+                               x->d_dist, ld);
+        }
+        {
+            Prof p(x, I_SELECT);
+            hipLaunchKernelGGL(select_small_kernel, dim3(nq), dim3(256), 0, x->stream, x->d_dist, ld, n, k, d_ids, d_dist_out, x->tie());
+        }
+        VQ_HIP(hipGetLastError());
+        x->stats[0] = 0; x->stats[1] = 0; x->stats[2] = nq;
+        x->stats_pending = false;
+        return 0;
+    }
     const int nchunks = cdiv(n, SEL_CHUNK);
     VQ_TRY(reserve_buf(x->d_partial, x->partial_cap, (int64_t)std::min(qslice, nq) * nchunks * k));
     for (int q0 = 0; q0 < nq; q0 += qslice) {
@@ -190,7 +220,31 @@ static bool large_qpw4() {          // $VQ_AMD_RESCORE_QPW4=1: the four-queries-
     return v;
 }
 
-int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out) {
+// The exact redo of the queries whose proof did not close (knn_fallback.h), sized from the device-side flagged count.
+void launch_fallback(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out, const int32_t* counters) {
+    const int64_t n = x->size;
+    const int fast_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_FAST_ROWS)));
+    const int64_t fast_rows = round_up(cdiv(n, fast_splits), FB_TILE);
+    const int fb_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_SPLIT_ROWS)));
+    const int64_t fb_rows = round_up(cdiv(n, fb_splits), FB_TILE);
+    const int64_t fb_cap = std::max<int64_t>(FB_QG, std::min<int64_t>(round_up(nq, FB_QG), ((int64_t)64 << 20) / ((int64_t)fb_splits * k * 8) / FB_QG * FB_QG));
+    Prof p(x, I_EXACT_DIST);
+    hipLaunchKernelGGL(exact_fallback_kernel, dim3(fast_splits, 1), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
+                       d_queries, x->d_slots, counters, 0, FB_FAST_SLOTS, k, fast_rows, x->d_fb_partial, x->tie());
+    hipLaunchKernelGGL(fallback_merge_kernel, dim3(FB_FAST_SLOTS), dim3(256), 0, x->stream, x->d_fb_partial, fast_splits, k, x->d_slots,
+                       counters, 0, FB_FAST_SLOTS, d_ids, d_dist_out, x->tie());
+    for (int64_t base = FB_FAST_SLOTS; base < nq; base += fb_cap) {
+        hipLaunchKernelGGL(exact_fallback_kernel, dim3(fb_splits, FB_SLOT_LANES), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
+                           d_queries, x->d_slots, counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial, x->tie());
+        hipLaunchKernelGGL(fallback_merge_kernel, dim3(64), dim3(256), 0, x->stream, x->d_fb_partial, fb_splits, k, x->d_slots,
+                           counters, (int)base, (int)fb_cap, d_ids, d_dist_out, x->tie());
+    }
+}
+
+// host_sync: the caller (vq_index_search) waits for the stream anyway, so the outcome counters are written by the kernels into
+// host-visible memory and the fallback launches are left to it — it reads the flagged count after its one wait and launches
+// them only when there is something to redo (normally nothing: two launches and a copy command fewer per search).
+int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_ids, float* d_dist_out, bool host_sync = false) {
     const int64_t n = x->size;
     // small batches (the reference's one-query-at-a-time search, video_search_system.py:297) take the HBM-bound
     // streaming scan; the 256-query MFMA tile is for batches
@@ -211,8 +265,10 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     VQ_TRY(reserve_buf(x->d_slots, x->slots_cap, round_up(nq, 1024)));
     if (!x->d_counters) {
         VQ_HIP(hipMalloc((void**)&x->d_counters, FB_NCOUNTERS * 4));
-        VQ_HIP(hipHostMalloc((void**)&x->h_counters, FB_NCOUNTERS * 4));
+        VQ_HIP(hipHostMalloc((void**)&x->h_counters, FB_NCOUNTERS * 4, hipHostMallocMapped));
+        VQ_HIP(hipHostGetDevicePointer((void**)&x->d_counters_host, x->h_counters, 0));
     }
+    int32_t* const counters = host_sync ? x->d_counters_host : x->d_counters;
     // Device-side fallback geometry.  First round: the first FB_FAST_SLOTS flagged queries over fine row splits (many
     // short workgroups: the usual handful of unproven queries is back in ~0.1 ms); bulk rounds: the rest over coarse
     // splits, as many flagged queries per round as 64 MiB of per-split lists hold.  One scratch buffer serves both.
@@ -221,6 +277,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     const int fb_splits = (int)std::max<int64_t>(1, std::min<int64_t>(FB_MAX_SPLITS, cdiv(n, FB_SPLIT_ROWS)));
     const int64_t fb_rows = round_up(cdiv(n, fb_splits), FB_TILE);
     const int64_t fb_cap = std::max<int64_t>(FB_QG, std::min<int64_t>(round_up(nq, FB_QG), ((int64_t)64 << 20) / ((int64_t)fb_splits * k * 8) / FB_QG * FB_QG));
+    (void)fast_rows; (void)fb_rows;                     // (launch_fallback derives the same geometry)
     VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, std::max<int64_t>(fb_cap * fb_splits, (int64_t)FB_FAST_SLOTS * fast_splits) * k));
     const int ranges = (int)(n_pad / RANGE);
     if (ver == 3) {
@@ -313,7 +370,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
             else if (ver == 3)
                 hipLaunchKernelGGL(rescore_verify_small_kernel, dim3(cur), dim3(256), (size_t)(RV_C * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
                                    x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
-                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? x->d_counters : nullptr, x->tie());
+                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? counters : nullptr, x->tie());
             else
             hipLaunchKernelGGL(rescore_verify_kernel, dim3(cdiv(cur, RV_QPW)), dim3(256), 0, x->stream, x->d_keys, streams,
                                q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
@@ -326,27 +383,17 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // nothing here waits for the stream.  Rounds beyond the first exist only when more queries could be flagged than
     // one round's scratch holds.
     if (!(ver == 3 && nq == 1 && k <= RV_K_SMALL))   // a single query's (small-k) re-score workgroup has written the list and the counters itself
-        hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, x->d_counters);
-    {
-        Prof p(x, I_EXACT_DIST);
-        hipLaunchKernelGGL(exact_fallback_kernel, dim3(fast_splits, 1), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
-                           d_queries, x->d_slots, x->d_counters, 0, FB_FAST_SLOTS, k, fast_rows, x->d_fb_partial, x->tie());
-        hipLaunchKernelGGL(fallback_merge_kernel, dim3(FB_FAST_SLOTS), dim3(256), 0, x->stream, x->d_fb_partial, fast_splits, k, x->d_slots,
-                           x->d_counters, 0, FB_FAST_SLOTS, d_ids, d_dist_out, x->tie());
-        for (int64_t base = FB_FAST_SLOTS; base < nq; base += fb_cap) {
-            hipLaunchKernelGGL(exact_fallback_kernel, dim3(fb_splits, FB_SLOT_LANES), dim3(FB_TILE), 0, x->stream, x->rows, n, x->dim,
-                               d_queries, x->d_slots, x->d_counters, (int)base, (int)fb_cap, k, fb_rows, x->d_fb_partial, x->tie());
-            hipLaunchKernelGGL(fallback_merge_kernel, dim3(64), dim3(256), 0, x->stream, x->d_fb_partial, fb_splits, k, x->d_slots,
-                               x->d_counters, (int)base, (int)fb_cap, d_ids, d_dist_out, x->tie());
-        }
-    }
+        hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, counters);
+    VQ_HIP(hipGetLastError());
+    if (host_sync) { x->fb_deferred = true; x->stats_pending = false; return 0; }
+    launch_fallback(x, d_queries, nq, k, d_ids, d_dist_out, counters);
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipMemcpyAsync(x->h_counters, x->d_counters, FB_NCOUNTERS * 4, hipMemcpyDeviceToHost, x->stream));
     x->stats_pending = true;
     return 0;
 }
 
-int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist) {
+int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode, int32_t* d_ids, float* d_dist, bool host_sync = false) {
     VQ_CHECK(mode >= 0 && mode <= 2, "vq_index_search: mode %d unknown", mode);
     VQ_CHECK(x->rank_n == 0 || x->rank_n == x->size, "vq_index_search: the id ranks cover %lld rows, the index holds %lld "
              "(call vq_index_set_id_ranks again after adding rows, or clear them)", (long long)x->rank_n, (long long)x->size);
@@ -358,7 +405,7 @@ int search_dispatch(vq_index* x, const float* d_queries, int nq, int k, int mode
                                      "(0.5 <= |row|^2 <= 2; rows added with normalize=0 are measured)", RV_K_MAX);
     // auto: the MFMA scan pays once the matrix is large enough to amortise its fixed costs
     const bool use_fp16 = mode == 2 || (mode == 0 && fp16_ok && x->size >= 16384);
-    return use_fp16 ? search_fp16(x, d_queries, nq, k, d_ids, d_dist) : search_exact(x, d_queries, nq, k, d_ids, d_dist);
+    return use_fp16 ? search_fp16(x, d_queries, nq, k, d_ids, d_dist, host_sync) : search_exact(x, d_queries, nq, k, d_ids, d_dist);
 }
 
 }  // namespace
@@ -413,6 +460,8 @@ int vq_index_destroy(vq_index* x) {
     (void)hipFree(x->d_q16); (void)hipFree(x->d_keys); (void)hipFree(x->d_flags); (void)hipFree(x->d_slots);
     (void)hipFree(x->d_counters); (void)hipFree(x->d_fb_partial); (void)hipFree(x->d_upd);
     if (x->h_counters) (void)hipHostFree(x->h_counters);
+    if (x->h_q) (void)hipHostFree(x->h_q);
+    if (x->h_res) (void)hipHostFree(x->h_res);
     (void)hipFree(x->d_norm_range); (void)hipFree(x->d_rank);
     delete x;
     return 0;
@@ -582,6 +631,46 @@ int vq_index_search(vq_index* x, const float* queries, int nq, int k, int mode, 
         return 0;
     }
     VQ_TRY(reserve_buf(x->d_q, x->q_cap, (int64_t)nq * x->dim));
+    const int64_t q_bytes = (int64_t)nq * x->dim * 4, res_bytes = (int64_t)nq * k * 8;
+    static const bool host_fast = !(getenv("VQ_AMD_HOST_FAST") && atoi(getenv("VQ_AMD_HOST_FAST")) == 0);      // A/B switch
+    if (host_fast && q_bytes <= ((int64_t)256 << 10) && res_bytes <= ((int64_t)16 << 10)) {      // (larger results: scattered 4-byte stores across PCIe lose to one copy)
+        // The reference caller's call (one query, k * 2 results: video_search_system.py:297) and small batches: the query goes up
+        // from pinned staging, the kernels write ids | distances straight into pinned, device-mapped host memory, and the ONE
+        // wait below is the only host/device round trip — no copy-back commands, no fallback launches unless a query was flagged.
+        if (q_bytes > x->hq_cap) {
+            if (x->h_q) (void)hipHostFree(x->h_q);
+            x->h_q = nullptr; x->hq_cap = 0;
+            VQ_HIP(hipHostMalloc((void**)&x->h_q, (size_t)std::max<int64_t>(q_bytes, 64 << 10)));
+            x->hq_cap = std::max<int64_t>(q_bytes, 64 << 10);
+        }
+        if (res_bytes > x->hres_cap) {
+            VQ_HIP(hipStreamSynchronize(x->stream));
+            if (x->h_res) (void)hipHostFree(x->h_res);
+            x->h_res = nullptr; x->hres_cap = 0;
+            VQ_HIP(hipHostMalloc((void**)&x->h_res, (size_t)std::max<int64_t>(res_bytes, 64 << 10), hipHostMallocMapped));
+            VQ_HIP(hipHostGetDevicePointer((void**)&x->d_res, x->h_res, 0));
+            x->hres_cap = std::max<int64_t>(res_bytes, 64 << 10);
+        }
+        memcpy(x->h_q, queries, (size_t)q_bytes);
+        VQ_HIP(hipMemcpyAsync(x->d_q, x->h_q, (size_t)q_bytes, hipMemcpyHostToDevice, x->stream));
+        int32_t* r_ids = (int32_t*)x->d_res;
+        float* r_dist = (float*)(x->d_res + (size_t)nq * k * 4);
+        x->fb_deferred = false;
+        VQ_TRY(search_dispatch(x, x->d_q, nq, k, mode, r_ids, r_dist, true));
+        VQ_HIP(hipStreamSynchronize(x->stream));
+        if (x->fb_deferred) {
+            x->fb_deferred = false;
+            for (int i = 0; i < 3; ++i) x->stats[i] = x->h_counters[1 + i];
+            if (x->h_counters[0] > 0) {                      // some proof did not close: the exact redo, then one more wait
+                launch_fallback(x, x->d_q, nq, k, r_ids, r_dist, x->d_counters_host);
+                VQ_HIP(hipGetLastError());
+                VQ_HIP(hipStreamSynchronize(x->stream));
+            }
+        }
+        memcpy(ids, x->h_res, (size_t)nq * k * 4);
+        memcpy(dist, x->h_res + (size_t)nq * k * 4, (size_t)nq * k * 4);
+        return 0;
+    }
     if ((int64_t)nq * k > x->out_cap) {
         int64_t c1 = x->out_cap, c2 = x->out_cap;
         VQ_TRY(reserve_buf(x->d_ids, c1, (int64_t)nq * k));
