@@ -648,6 +648,11 @@ def main():
         "sustained": sustained,
         "sustained_frames_per_s": sustained["frames_per_s"] if sustained else None,
         "encode_mfma_frac_whole_pass": frames_per_s / world * flop_per_frame / PEAK_BF16,
+        # The chip does not hold the 2.4 GHz the 2.5 PFLOP/s peak is priced at while MFMAs run on non-zero data: s_memtime / s_memrealtime
+        # stamps inside the tower's K loops (a DIAGNOSTIC build, three batches in flight: profiles/r02c_tower_stamps_3streams.txt) read
+        # 1.86-1.87 GHz.  A replayed figure of the same kernels, not a measurement of this run; the fraction against the peak at that clock:
+        "encode_clock_held": {"ghz": 1.87, "priced_at_ghz": 2.4, "source": "profiles/r02c_tower_stamps_3streams.txt (diagnostic-build stamps; replayed, not measured in this run)",
+                              "mfma_frac_whole_pass_at_held_clock": frames_per_s / world * flop_per_frame / (PEAK_BF16 * 1.87 / 2.4)},
         # the last block's out_proj/LN2/MLP run on the CLS rows only (outputs identical): executed work per frame
         "flop_per_frame": {"algorithmic": flop_per_frame,
                            "executed": flop_per_frame - (0 if os.environ.get("VQ_AMD_FULL_LAST_LAYER") == "1"

@@ -6,14 +6,27 @@ instantiate gemm_tn256a_kernel to device assembly and fails if, in any instantia
     that accumulator out (it may use an AGPR as spill space once its accumulator has been consumed),
   * there is a backward branch between the loop and the last read (program order would not be execution order), or
   * the kernel uses scratch.
-usage: python scripts/check_asm256.py [vq_core.hip vq_encoder.hip ...]   (default: the TUs of the product library that use it)"""
+usage: python scripts/check_asm256.py [--hipcc PATH] [--flags "the build's CXXFLAGS"] [vq_core.hip vq_encoder.hip ...]
+`make DIAG=1` (the only builds that contain the kernel since round 4) runs it with its own $(HIPCC) and $(CXXFLAGS), so what is
+checked is the compile that ships; run by hand it defaults to the Makefile's defaults plus -DVQ_DIAG."""
 import os, re, subprocess, sys, tempfile
 
 here = os.path.dirname(os.path.abspath(__file__))
 csrc = os.path.join(here, '..', 'video-quierer_amd', 'csrc')
-tus = [a for a in sys.argv[1:] if not a.startswith('-')] or ['vq_core.hip', 'vq_encoder.hip']
-extra = [a for a in sys.argv[1:] if a.startswith('-')]
-flags = '-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-cuda-compat -ffp-contract=on --cuda-device-only -S'.split() + extra
+argv = sys.argv[1:]
+hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+flags = None
+while argv and argv[0] in ('--hipcc', '--flags'):
+    if argv[0] == '--hipcc':
+        hipcc = argv[1]
+    else:
+        flags = argv[1].split()
+    argv = argv[2:]
+tus = [a for a in argv if not a.startswith('-')] or ['vq_core.hip', 'vq_encoder.hip', 'vq_diag.hip']
+if flags is None:
+    objdir = os.path.join(csrc, '..', 'lib', 'obj_diag')
+    flags = f'-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-cuda-compat -ffp-contract=on -DVQ_DIAG -I{objdir}'.split()
+flags = [f for f in flags if f != '-c'] + [a for a in argv if a.startswith('-')] + ['--cuda-device-only', '-S']
 
 
 def check(name, text):
@@ -62,7 +75,7 @@ bad, seen = 0, 0
 for tu in tus:
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'tu.s')
-        subprocess.run(['/opt/rocm/bin/hipcc'] + flags + [os.path.join(csrc, tu), '-o', out], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([hipcc] + flags + [os.path.join(csrc, tu), '-o', out], check=True)
         txt = open(out).read()
     for f in re.split(r'\n\t\.globl\t', txt):
         name = f.split('\n', 1)[0]

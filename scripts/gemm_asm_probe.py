@@ -56,5 +56,9 @@ for name, m, n, k, epi in cases:
             us, mhz, cpt = clocked(m, n, k, epi, mode)
             print(f"{'':16s} kernel 24 {what}: {us:.1f} us, {mhz} MHz inside the K loop, {cpt:.0f} cycles per K-tile (= {cpt / mhz:.3f} us)", flush=True)
     if os.environ.get("VQ_PROBE_ABLATE") and epi == 0:
-        ab = {v: np.median([run(m, n, k, 24, epi, mode=v) for _ in range(3)]) * 1e3 for v in (1, 2, 3, 4, 5)}
+        ab = {v: np.median([run(m, n, k, 24, epi, mode=v) for _ in range(3)]) * 1e3 for v in (1, 2, 3, 4, 5, 6, 7)}
+        t0 = np.median([run(m, n, k, 24, epi, mode=0) for _ in range(3)]) * 1e3
+        print(f"{'':16s} the batch scan's top-2 fold in this four-wave form (a quarter of a row tile's fold per two K-tiles, results invalid): "
+              f"product loop {t0:.1f} us, + fold as a burst behind the accumulators' last MFMAs {ab[6]:.1f} ({ab[6] / t0:.3f}x), "
+              f"+ fold spread one instruction per MFMA {ab[7]:.1f} ({ab[7] / t0:.3f}x)", flush=True)
         print(f"{'':16s} ablations of kernel 24 (results invalid): no DMA {ab[1]:.1f} us ({fl / ab[1] / 1e6:.0f}), no DMA + no fragment reads {ab[2]:.1f} ({fl / ab[2] / 1e6:.0f}), every wave in the same DMA slots {ab[3]:.1f} ({fl / ab[3] / 1e6:.0f}), no MFMAs {ab[4]:.1f}, no MFMAs + no fragment reads {ab[5]:.1f}", flush=True)

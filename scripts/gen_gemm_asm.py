@@ -112,6 +112,28 @@ def tile(p, kind, sched, w):
             if not no_reads:
                 put(64 + sched['rd1_first'] + n * sched['rd1_stride'], ins)
         put(64 + 61, 's_waitcnt lgkmcnt(0)')
+    # timing ablations 6 / 7 (diagnostic builds): what the batch scan's top-2 fold (knn_scan_fold.h: per score a key = score bits |
+    # row index, m2 = med3(m1, m2, key), m1 = max(m1, key)) would cost in THIS four-wave form, where the 256 accumulators sit in
+    # AGPRs and a wave has no partner on its SIMD to hide vector work behind.  A row tile of the scan is 8 K-tiles; one loop
+    # iteration here is 2, so every iteration carries a QUARTER of a row tile's fold: 16 accumulator tiles x 4 scores x
+    # (v_accvgpr_read + 3) = 256 vector instructions.  fold=1: as a burst right behind those accumulators' last MFMAs (tile p = 1,
+    # k-half 1: what the live range of an accumulator allows - it is overwritten 64 MFMAs later); fold=2: one instruction behind
+    # every MFMA of the iteration (the unreachable best case: as if the values could wait in spare registers).
+    fold = sched.get('fold', 0)
+    if fold and kind == 'steady':
+        def score_ops(r, n):
+            t, m1, m2 = 100 + (n & 3), 104 + 2 * ((n >> 2) & 3), 105 + 2 * ((n >> 2) & 3)
+            return [f'v_accvgpr_read_b32 v{t}, a{r}', f'v_and_or_b32 v{t}, v{t}, v112, v113',
+                    f'v_med3_f32 v{m2}, v{m1}, v{m2}, v{t}', f'v_max_f32 v{m1}, v{m1}, v{t}']
+        if fold == 1 and p == 1:
+            for at in range(16):                                   # accumulator tile `at`: last MFMA at slot 64 + at
+                ops = [o for e in range(4) for o in score_ops(4 * at + e, 4 * at + e)]
+                for n, o in enumerate(ops):
+                    put(min(127, 64 + at + 2 + n // 8), o)
+        if fold == 2:
+            ops = [o for at in range(8) for e in range(4) for o in score_ops(4 * ((at + 24 + 32 * p) % 64) + e, 4 * at + e)]
+            for n, o in enumerate(ops):
+                put(n, o)
     out = []
     for s in range(128):
         if not sched.get('no_mfma', 0):
@@ -176,6 +198,8 @@ VARIANTS = [            # (macro suffix, overrides): variant 0 is the product sc
     ('3', dict(same_slots=1)),
     ('4', dict(no_mfma=1)),
     ('5', dict(no_mfma=1, no_reads=1)),
+    ('6', dict(fold=1)),
+    ('7', dict(fold=2)),
 ]
 
 
@@ -230,6 +254,8 @@ def main():
             for name, over in VARIANTS[1:]:
                 sched = dict(base); sched.update(over)
                 write_text(f, name, build(sched))
+            f.write('// registers the fold ablations (6, 7) use beside the product text\n')
+            f.write('#define VQ_A256_DIAG_CLOBBERS , ' + ', '.join(f'"v{i}"' for i in range(100, 116)) + '\n')
         print(diag_path)
 
 

@@ -33,6 +33,9 @@
 #include "gemm_asm256_loop.inc"
 #ifdef VQ_DIAG
 #include "gemm_asm256_loop_diag.inc"      // generated into $(OBJDIR) by `make DIAG=1` (scripts/gen_gemm_asm.py --diag)
+#define VQ_A256_MORE_CLOBBERS VQ_A256_DIAG_CLOBBERS
+#else
+#define VQ_A256_MORE_CLOBBERS
 #endif
 
 namespace vq {
@@ -205,7 +208,7 @@ void gemm_tn256a_kernel(const uint16_t* __restrict__ A, int lda,
                      : [srd_a0] "s"(srd_a0), [srd_a1] "s"(srd_a1), [srd_w0] "s"(srd_w0), [srd_w1] "s"(srd_w1),                \
                        [a_v0] "v"(a_v0), [w_v0] "v"(w_v0), [rd_a] "v"(rd_a), [rd_w] "v"(rd_w),                                \
                        [m0_a] "s"(m0_a), [trips] "s"(trips), [a_row8] "s"(a_row8_s), [w_row8] "s"(w_row8_s), [wave] "s"(wave)  \
-                     : "memory", "scc", VQ_A256_CLOBBERS)
+                     : "memory", "scc", VQ_A256_CLOBBERS VQ_A256_MORE_CLOBBERS)
 #define VQ_A256_RUN_TY(NAME) do { if constexpr (IS_F16) VQ_A256_RUN(NAME("f16")); else VQ_A256_RUN(NAME("bf16")); } while (0)
 #ifdef VQ_DIAG
         if constexpr (V == 1) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_1);
@@ -213,6 +216,8 @@ void gemm_tn256a_kernel(const uint16_t* __restrict__ A, int lda,
         else if constexpr (V == 3) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_3);
         else if constexpr (V == 4) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_4);
         else if constexpr (V == 5) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_5);
+        else if constexpr (V == 6) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_6);
+        else if constexpr (V == 7) VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_7);
         else
 #endif
         VQ_A256_RUN_TY(VQ_A256_LOOP_TEXT_0);

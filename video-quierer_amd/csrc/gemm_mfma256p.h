@@ -30,7 +30,9 @@
 #include "gemm_mfma128x256p.h"
 #endif
 #include "gemm_mfma256f.h"
+#ifdef VQ_DIAG       // the hand-scheduled four-wave kernel (id 24) changed nothing in frames/s (DESIGN.md section 4 "Round 3" (5)): diagnostic builds only
 #include "gemm_asm256.h"
+#endif
 
 namespace vq {
 
@@ -315,8 +317,12 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
                             int M, int N, int K, const Epi& epi, int force = 0) {
     // 24: the hand-scheduled four-wave 256x256 mainloop (gemm_asm256.h) on every shape that tiles
     if (force == 24) {
+#ifdef VQ_DIAG
         if (M % G2_BM == 0 && N % G2_BN == 0 && K % (2 * G2_BK) == 0) return launch_gemm_tn256a<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         force = 6;
+#else
+        return fail(VQ_ERR_INVALID, "gemm kernel 24 (hand-scheduled four-wave loop) is built into diagnostic libraries only: `make DIAG=1 OUT=... OBJDIR=...`");
+#endif
     }
     // 20 / 21: persistent out-of-phase 128x256 tiles, two workgroups per CU (gemm_mfma128x256p.h), on every shape that tiles
     // (20: the second workgroup of a CU starts half a tile late; 21: no lag — the in-step control of the A/B)

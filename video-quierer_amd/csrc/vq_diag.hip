@@ -209,6 +209,8 @@ int vq_debug_gemm_bench(int M, int N, int K, int kernel, int mode, int dephase_c
                 if (mode == 3) return launch_gemm_tn256a<true, decltype(e), 3>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
                 if (mode == 4) return launch_gemm_tn256a<true, decltype(e), 4>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
                 if (mode == 5) return launch_gemm_tn256a<true, decltype(e), 5>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 6) return launch_gemm_tn256a<true, decltype(e), 6>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
+                if (mode == 7) return launch_gemm_tn256a<true, decltype(e), 7>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
                 return launch_gemm_tn256a<true>(nullptr, dA, K, dW, K, M, N, K, e, census ? dS : nullptr);
             }
             return fail(VQ_ERR_INVALID, "vq_debug_gemm_bench: kernel %d is not available in this build", kernel);

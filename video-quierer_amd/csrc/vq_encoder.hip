@@ -479,7 +479,9 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     vq_encoder* e = new vq_encoder();
     if (flags & VQ_ENC_CONCURRENT) e->gemm_force = 6;        // auto, without the 160-row tiles
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
+#endif
     if (const char* at = getenv("VQ_AMD_ATTN")) { e->attn_simple = !strcmp(at, "simple"); e->attn_q64 = !strcmp(at, "q64"); }
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->f16_mask = dtype_mask_from(flags);
@@ -589,7 +591,9 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->patch_unscale = parent->patch_unscale;
     e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
+#endif
     e->attn_simple = parent->attn_simple; e->attn_q64 = parent->attn_q64; e->prune_last = parent->prune_last;
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = round_up((int64_t)max_batch * e->patches, 256);
@@ -652,7 +656,9 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
+#endif
     e->f16_mask = dtype_mask_from(flags);
     auto cleanup = [&](int rc) { vq_encoder_destroy(e); return rc; };
 
