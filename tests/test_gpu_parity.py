@@ -199,6 +199,32 @@ def test_encoder_hand_scheduled_gemms_are_bit_identical(gpu_lib, b32_weights, mo
     assert np.sum(out["31", True][:8] * ref, axis=1).min() >= 1.0 - COS_TOL
 
 
+def test_encoder_16_plus_16_bit_residual_stream(gpu_lib, b32_weights, golden_encoder, monkeypatch):
+    """[r04] Between the residual epilogues the stream lives as xh = fp16(x) (the next GEMM's operand, written anyway) and
+    xl = fp16(x - xh) instead of the fp32 x (EpiBiasResidualLnF32 modes; -20 % of the bytes of the two HBM-bound epilogues).
+    The pair carries ~22 bits: against the all-fp32 stream ($VQ_AMD_RESID=f32) the embeddings move by far less than the fp16
+    operands' own rounding, and both stay inside the golden tolerance; outlier channels included."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    from conftest import outlier_weights
+    frames = synth_frames(64)
+    for W, gold in ((b32_weights, golden_encoder["embeddings"]), (outlier_weights(), None)):
+        out = {}
+        for mode in ("f32", "split"):
+            monkeypatch.setenv("VQ_AMD_RESID", mode)
+            enc = VitEncoder(VIT_B_32, W, max_batch=64)
+            out[mode] = enc.encode(frames)
+            enc.close()
+        monkeypatch.delenv("VQ_AMD_RESID")
+        d = float(np.abs(out["split"] - out["f32"]).max())
+        print(f"16+16-bit residual stream vs fp32 stream: max |delta embedding| = {d:.2e}")
+        assert d <= 5e-5, d
+        assert not np.array_equal(out["split"], out["f32"])               # (the switch does switch)
+        if gold is not None:
+            for o in out.values():
+                assert np.abs(np.sum(o * gold, axis=1) - 1.0).max() <= COS_TOL
+
+
 def test_shared_weight_handles(gpu_lib, b32_weights):
     """vq_encoder_create_shared: clones run on the parent's device weights with their own stream and workspace; results
     are bit-identical to the parent's (same kernels), concurrent use is safe, and either side may be closed first."""

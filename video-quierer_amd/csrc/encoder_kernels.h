@@ -104,17 +104,64 @@ constexpr int LN_MAX_GRANULES = 16;                     // hidden <= 1024
 struct LnPartials { float2* ps; int64_t stride; };     // ps[g * stride + row], g = column / 64; LN_MAX_GRANULES planes, unused ones stay zero
 
 // x += acc + bias (fp32), xh = 16-bit(x), row partials -> ps          (producer: out_proj / fc2)
-template <int SITE, bool F16>
+//
+// [r04] The residual stream as 16 + 16 bits.  xh = fp16(x) IS the next GEMM's operand and is written anyway; with
+// xl = fp16(x - xh) beside it the pair carries x to ~22 bits (fp32 has 24), so the fp32 copy need not be written — and
+// the next residual epilogue reads xh + xl (4 bytes per element, as before) instead of x.  Per element an epilogue then
+// moves 4 B in + 4 B out instead of 4 B in + 6 B out: -20 % of the bytes of the two HBM-bound epilogues of the tower
+// (out_proj: 130 -> 111 MB per launch for 15 GFLOP, fc2 222 -> 205 MB: PMC).  MODE bits: RS_IN_SPLIT (read xh + xl, else
+// the fp32 x), RS_OUT_SPLIT (write xl), RS_OUT_F32 (write the fp32 x).  The first residual epilogue of a pass reads the fp32 x
+// the embedding kernel wrote; the last one before a consumer of x itself (the pooling head, the CLS-only last block) writes it
+// again.  fp16 operands only (F16): with bf16 operands xh has 8 bits and the pair 16.
+// (v_fma_mix_f32 for hi + lo and y - hi — one instruction per element instead of conversions + add — was built and measured:
+//  same time to 0.1 us, so the plain form stays.)
+// Streaming (nt) stores for epilogue outputs that are far larger than the L2s and consumed by the NEXT kernel: the q|k|v and MLP
+// activations (59 / 79 MB per launch).  Written through the L2 like ordinary data they displace the operand panels the GEMM is
+// re-reading — PMC, one batch at a time: qkv 151.0 -> 119.6 MB from beyond L2 per launch, fc1 183.9 -> 165.5 MB; 64.9 -> 60.9 us
+// and 74.9 -> 71.3 us; three batches in flight 100.9k -> 101.6-102.2k frames/s (profiles/r04_ab_nt_store/).  On the residual
+// epilogues' xh / xl (read back soon) they change nothing.  Build-time switches so that variants can be A/B-ed as separate libraries.
+#ifndef VQ_EPI_LN_NT_STORE
+#define VQ_EPI_LN_NT_STORE 1
+#endif
+#ifndef VQ_EPI_RES_NT_STORE
+#define VQ_EPI_RES_NT_STORE 0
+#endif
+__device__ __forceinline__ void st8_maybe_nt(uint16_t* p, uint2 v) {
+#if VQ_EPI_RES_NT_STORE
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    __builtin_nontemporal_store(u32x2{v.x, v.y}, (u32x2*)p);
+#else
+    *(uint2*)p = v;
+#endif
+}
+enum : int { RS_IN_SPLIT = 1, RS_OUT_SPLIT = 2, RS_OUT_F32 = 4, RS_F32 = RS_OUT_F32 };
+__device__ __forceinline__ f32x4 unpack4_f16(uint2 u) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 h = __builtin_bit_cast(h4, u);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <int SITE, bool F16, int MODE = RS_F32>
 struct EpiBiasResidualLnF32 {
-    float* x; int ldx; const float* bias; uint16_t* xh; LnPartials part;
+    float* x; int ldx; const float* bias; uint16_t* xh; LnPartials part; uint16_t* xl = nullptr;
+    static_assert(MODE == RS_F32 || F16, "the 16 + 16-bit residual stream needs fp16 operands");
     static constexpr bool kLoads = true, kRowStats = true;
     __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(bias + n); }
-    __device__ __forceinline__ f32x4 load(int m, int n) const { return ld4(x + (size_t)m * ldx + n); }
+    __device__ __forceinline__ f32x4 load(int m, int n) const {
+        if constexpr (MODE & RS_IN_SPLIT) {
+            const size_t o = (size_t)m * ldx + n;
+            return unpack4_f16(*(const uint2*)(xh + o)) + unpack4_f16(*(const uint2*)(xl + o));
+        } else {
+            return ld4(x + (size_t)m * ldx + n);
+        }
+    }
     __device__ __forceinline__ void store(int, int, f32x4, f32x4, f32x4) const {}
     __device__ __forceinline__ f32x4 store_stats(int m, int n, f32x4 v, f32x4 b, f32x4 r) const {
         const f32x4 y = r + v + b;
-        *(f32x4*)(x + (size_t)m * ldx + n) = y;
-        *(uint2*)(xh + (size_t)m * ldx + n) = pack4_h<F16>(y);
+        const size_t o = (size_t)m * ldx + n;
+        if constexpr (MODE & RS_OUT_F32) *(f32x4*)(x + o) = y;
+        const uint2 hi = pack4_h<F16>(y);
+        st8_maybe_nt(xh + o, hi);
+        if constexpr (MODE & RS_OUT_SPLIT) st8_maybe_nt(xl + o, pack4_h<true>(y - unpack4_f16(hi)));
         return y;
     }
     __device__ __forceinline__ void put_stats(int m, int n_wave0, float s1, float s2) const {
@@ -175,7 +222,11 @@ struct EpiLnH16 {
             if constexpr (GELU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * y));
             v[i] = y;
         }
+#if VQ_EPI_LN_NT_STORE
+        { typedef __attribute__((ext_vector_type(2))) unsigned int u32x2; const uint2 pk = pack4_h<F16>(v); __builtin_nontemporal_store(u32x2{pk.x, pk.y}, (u32x2*)(out + (size_t)m * ldo + n)); }
+#else
         *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
+#endif
     }
     __device__ __forceinline__ void store_ln8(int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, f32x4 a0, f32x4 a1, float2 st) const {
 #pragma unroll
@@ -189,7 +240,12 @@ struct EpiLnH16 {
             v0[i] = y0; v1[i] = y1;
         }
         const uint2 lo = pack4_h<F16>(v0), hi = pack4_h<F16>(v1);
+#if VQ_EPI_LN_NT_STORE
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y}, (u32x4*)(out + (size_t)m * ldo + n));
+#else
         *(uint4*)(out + (size_t)m * ldo + n) = uint4{lo.x, lo.y, hi.x, hi.y};
+#endif
     }
 };
 

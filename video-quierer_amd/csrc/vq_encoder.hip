@@ -69,6 +69,8 @@ struct vq_encoder {
     uint8_t* d_frames = nullptr;
     float *x = nullptr, *d_out = nullptr;
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;      // h = xh: the residual stream rounded to 16 bits
+    uint16_t* xl = nullptr;                    // [r04] fp16(x - xh): with xh the residual stream at 16 + 16 bits (EpiBiasResidualLnF32 modes)
+    bool split_resid = true;                   // $VQ_AMD_RESID=f32: every residual epilogue reads and writes the fp32 x (rounds 1-3; the A/B switch)
     float2* ps = nullptr;                      // LayerNorm row partials [hidden/64][rows_pad]
     uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned staging slots (lazy)
     float* h_out_stage = nullptr;               // pinned result buffer
@@ -129,7 +131,7 @@ size_t arena_bytes(const vq_vit_config& c, int tokens, int patches, int patch_k,
     add((size_t)max_batch * c.image_size * c.image_size * 3);
     add((size_t)LN_MAX_GRANULES * rows_pad * 8);
     add((size_t)rows_pad * h * 4); add((size_t)max_batch * c.proj_dim * 4);
-    add((size_t)rows_pad * h * 2); add((size_t)rows_pad * 3 * h * 2); add((size_t)rows_pad * h * 2);
+    add((size_t)rows_pad * h * 2); add((size_t)rows_pad * h * 2); add((size_t)rows_pad * 3 * h * 2); add((size_t)rows_pad * h * 2);
     size_t mlp_elems = std::max((size_t)rows_pad * m, (size_t)prow_pad * patch_k);
     add(mlp_elems * 2);
     (void)patches;
@@ -292,6 +294,18 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
     }
     }
     e->h_is_f16 = fQ;
+    // [r04] the residual stream at 16 + 16 bits between the residual epilogues (encoder_kernels.h): fp16 operands in every group
+    // that writes xh, and not in layer-limited debug runs (vq_encoder_debug_read reads the fp32 x).  The first residual epilogue
+    // reads the embedding kernel's fp32 x; the last one in front of a reader of x (pooling head / the CLS-only last block) writes it.
+    const bool cls_last = !e->is_text && e->prune_last && e->run_layers < 0;
+    const bool split = e->split_resid && fQ && f1 && e->run_layers < 0;
+    bool stream_split = false;                                 // what the residual stream is held as right now
+    auto resid_mode = [&](bool wants_f32_after) {
+        if (!split) return (int)RS_F32;
+        const int m = (stream_split ? RS_IN_SPLIT : 0) | (wants_f32_after ? RS_OUT_F32 : RS_OUT_SPLIT);
+        stream_split = !wants_f32_after;
+        return m;
+    };
     for (int l = 0; l < nl; ++l) {
         const LayerW& L = e->layers[l];
         {   // E5/E6: LN1 (folded) + fused q|k|v projection (q pre-scaled by d_h^-0.5 through its weights) on xh
@@ -384,10 +398,15 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // out_proj + residual; writes xh and the row partials for the LN2 folded into fc1
             Prof p(e, C_GEMM_OUT);
+            const int mode = resid_mode(false);
             VQ_TRY(by_f16(fA, [&](auto F) {
                 return by_f16(f1, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H, 2), H, H,
-                                                       EpiBiasResidualLnF32<0, VQ_F16(FO)>{e->x, H, L.b_out, e->h, part}, gf(2, rows_gemm, H, H));
+                    auto go = [&](auto epi) { return launch_gemm_auto<VQ_F16(F)>(st, e->att, H, L.w_out, H, gemm_rows(H, H, 2), H, H, epi, gf(2, rows_gemm, H, H)); };
+                    if constexpr (VQ_F16(FO)) {
+                        if (mode == RS_OUT_SPLIT) return go(EpiBiasResidualLnF32<0, true, RS_OUT_SPLIT>{e->x, H, L.b_out, e->h, part, e->xl});
+                        if (mode == (RS_IN_SPLIT | RS_OUT_SPLIT)) return go(EpiBiasResidualLnF32<0, true, RS_IN_SPLIT | RS_OUT_SPLIT>{e->x, H, L.b_out, e->h, part, e->xl});
+                    }
+                    return go(EpiBiasResidualLnF32<0, VQ_F16(FO)>{e->x, H, L.b_out, e->h, part});
                 });
             }));
             e->h_is_f16 = f1;
@@ -404,10 +423,16 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
         }
         {   // fc2 + residual; writes xh and the row partials for the next block's folded LN1
             Prof p(e, C_GEMM_FC2);
+            // the fp32 x is wanted behind this epilogue when the pooling head comes next, or the CLS-only last block
+            const int mode = resid_mode(l == nl - 1 || (cls_last && l == c.layers - 2));
             VQ_TRY(by_f16(f2, [&](auto F) {
                 return by_f16(fQ, [&](auto FO) {
-                    return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp, 8), H, c.mlp,
-                                                       EpiBiasResidualLnF32<1, VQ_F16(FO)>{e->x, H, L.b_fc2, e->h, part}, gf(8, rows_gemm, H, c.mlp));
+                    auto go = [&](auto epi) { return launch_gemm_auto<VQ_F16(F)>(st, e->mlp, c.mlp, L.w_fc2, c.mlp, gemm_rows(H, c.mlp, 8), H, c.mlp, epi, gf(8, rows_gemm, H, c.mlp)); };
+                    if constexpr (VQ_F16(FO)) {
+                        if (mode == (RS_IN_SPLIT | RS_OUT_SPLIT)) return go(EpiBiasResidualLnF32<1, true, RS_IN_SPLIT | RS_OUT_SPLIT>{e->x, H, L.b_fc2, e->h, part, e->xl});
+                        if (mode == (RS_IN_SPLIT | RS_OUT_F32)) return go(EpiBiasResidualLnF32<1, true, RS_IN_SPLIT | RS_OUT_F32>{e->x, H, L.b_fc2, e->h, part, e->xl});
+                    }
+                    return go(EpiBiasResidualLnF32<1, VQ_F16(FO)>{e->x, H, L.b_fc2, e->h, part});
                 });
             }));
             e->h_is_f16 = fQ;
@@ -479,6 +504,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     vq_encoder* e = new vq_encoder();
     if (flags & VQ_ENC_CONCURRENT) e->gemm_force = 6;        // auto, without the 160-row tiles
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* rs = getenv("VQ_AMD_RESID")) e->split_resid = strcmp(rs, "f32") != 0;
     #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
 #endif
@@ -568,6 +594,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * patch_k));
@@ -591,6 +618,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->patch_unscale = parent->patch_unscale;
     e->gemm_force = (flags & VQ_ENC_CONCURRENT) ? 6 : 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* rs = getenv("VQ_AMD_RESID")) e->split_resid = strcmp(rs, "f32") != 0;
     #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
 #endif
@@ -608,7 +636,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     add((size_t)max_batch * c.image_size * c.image_size * 3);
     add((size_t)LN_MAX_GRANULES * e->rows_pad * 8);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * c.proj_dim * 4);
-    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
+    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
     add(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k) * 2);
     bytes += 4096;
     hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
@@ -626,6 +654,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k));
@@ -656,6 +685,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = 0;
     if (const char* gf = getenv("VQ_AMD_GEMM")) e->gemm_force = atoi(gf);
+    if (const char* rs = getenv("VQ_AMD_RESID")) e->split_resid = strcmp(rs, "f32") != 0;
     #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
 #endif
@@ -673,7 +703,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     add((size_t)LN_MAX_GRANULES * e->rows_pad * 8);
     add((size_t)max_batch * T * 4); add((size_t)max_batch * 4);
     add((size_t)e->rows_pad * H * 4); add((size_t)max_batch * t.proj_dim * 4);
-    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
+    add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * H * 2); add((size_t)e->rows_pad * 3 * H * 2); add((size_t)e->rows_pad * H * 2);
     add((size_t)e->rows_pad * M * 2);
     bytes += 4096;
     hipError_t he = hipMalloc((void**)&e->arena.base, bytes);
@@ -711,6 +741,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * t.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>((size_t)e->rows_pad * M);
