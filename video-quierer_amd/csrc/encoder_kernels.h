@@ -499,6 +499,21 @@ inline __global__ void eos_rows_kernel(const int* __restrict__ ids, int* __restr
 //                   key(s,g,j) = 32 s + 16 (j>>2) + 4 g + (j&3); V^T fragments in that same
 //                   order come from ds_read_b64_tr_b16 on a row-major [64 keys][64 d] LDS tile.
 // qkv: [rows][3*hidden] bf16 (q | k | v);  out: [rows][hidden] bf16.
+// q | k | v are read exactly once by the single-tile attention (59 MB per launch at batch 256): as streaming (nt) loads they do not
+// displace the operand panels that the GEMMs of the other batches in flight are re-reading from the same L2s.  Build-time A/B switch.
+#ifndef VQ_ATT_NT_LOAD
+#define VQ_ATT_NT_LOAD 0
+#endif
+__device__ __forceinline__ uint4 ld16_att(const uint16_t* p) {
+#if VQ_ATT_NT_LOAD
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return uint4{v[0], v[1], v[2], v[3]};
+#else
+    return *(const uint4*)p;
+#endif
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256)
 void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
@@ -521,7 +536,7 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     for (int it = 0; it < 8; ++it) {
         const int id = it * 64 + lane, row = id >> 3, c = id & 7;
         uint4 val = {0u, 0u, 0u, 0u};
-        if (row < tokens) val = *(const uint4*)(base + 2 * hidden + (size_t)row * ld + c * 8);
+        if (row < tokens) val = ld16_att(base + 2 * hidden + (size_t)row * ld + c * 8);
         *(uint4*)(vt + row * 64 + c * 8) = val;
     }
 
@@ -534,8 +549,8 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
         for (int ks = 0; ks < 2; ++ks) {
             uint4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
             if (row < tokens) {
-                kv = *(const uint4*)(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
-                qv = *(const uint4*)(base + (size_t)row * ld + ks * 32 + g * 8);
+                kv = ld16_att(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
+                qv = ld16_att(base + (size_t)row * ld + ks * 32 + g * 8);
             }
             kf[t][ks] = __builtin_bit_cast(frag, kv);
             qf[t][ks] = __builtin_bit_cast(frag, qv);

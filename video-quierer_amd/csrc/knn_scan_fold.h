@@ -34,6 +34,9 @@
 //
 // Staging, LDS image, key layout, streams: scan4's.  Results are bit-identical to scan4's keys.
 #pragma once
+#ifndef VQ_SCAN_NT_KEYS
+#define VQ_SCAN_NT_KEYS 0
+#endif
 #include "vq_common.h"
 #include "gemm_mfma.h"
 #include "gemm_mfma256.h"
@@ -323,7 +326,12 @@ void scan5_f16_top2_kernel(const uint16_t* __restrict__ Q16, const uint16_t* __r
     for (int mi = 0; mi < 8; ++mi) {
         const int q = m0 + wr * 128 + mi * 16 + frow;
         const float2 p = mm[mi * 64];
+#if VQ_SCAN_NT_KEYS      // the keys (625 MB per 10k x 1M batch, read once by the re-score kernel) as streaming stores: build-time A/B
+        { typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+          __builtin_nontemporal_store(u32x2{__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y)}, (u32x2*)(keys + batch_key_index(stream, q, (int64_t)n_ranges * 16))); }
+#else
         *(uint2*)(keys + batch_key_index(stream, q, (int64_t)n_ranges * 16)) = uint2{__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y)};
+#endif
     }
 }
 
