@@ -30,7 +30,7 @@ FLOP_PER_FRAME = 2 * 4_408_811_520          # 8.818 GFLOP / fram
 PEAK_BF16 = 2.5e15                          # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_FP16 = 2.5e15
 PEAK_HBM = 8.0e12
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json")   # newest first
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01d_pmc_traffic.json")   # newest first
 
 
 def pmc_bytes(*classes):

@@ -19,6 +19,8 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 python bench.py --workload config4 --steps 5 --warmup 2 > $O/bench_config4_1gpu.json 2>> $O/bench.err; echo "config4 done"
 VQ_BENCH_DEVICE=0 VQ_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-e2e > $O/bench_2rank_gloo_rehearsal.json 2>> $O/bench.err; echo "2-rank gloo rehearsal done"
 timeout -k 10 300 python scripts/search_latency.py > $O/search_latency.txt 2>&1; echo "search latency done"
+timeout -k 10 300 python scripts/host_latency_probe.py 2>&1 | grep -v amdgpu.ids > $O/host_latency.txt; echo "host latency done"
+timeout -k 10 300 python bench.py --model l14 --batch 32 --steps 12 --warmup 3 --no-search --no-preprocess --no-e2e > $O/bench_vit_l14_336.json 2>> $O/bench.err; echo "ViT-L/14@336 done"
 find $O -name '*kernel_stats.csv' | while read f; do cp $f $O/$(echo $f | sed 's#.*/\(prof[013]\)/.*#\1#')_kernel_stats.csv; done
 find $O -name '*_kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -size +20M -delete
 ls -la $O

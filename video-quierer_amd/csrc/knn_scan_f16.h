@@ -812,8 +812,9 @@ __device__ unsigned long long g_rs_stamps[16];
 #define VQ_RS_STAMP(i)
 #endif
 
+template <int C>
 __global__ __launch_bounds__(256)
-void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
+void rescore_verify_small_kernel_t(const uint32_t* __restrict__ keys, int64_t streams, int64_t q_pad,
                                  const float* __restrict__ rows, int64_t n_valid, int dim,
                                  const float* __restrict__ queries, int nq, int k,
                                  int32_t* __restrict__ out_ids, float* __restrict__ out_dist,
@@ -821,13 +822,16 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                                  int32_t* __restrict__ slots1 /* with counters1: a ONE-query launch writes the flagged list and */,
                                  int32_t* __restrict__ counters1 /* the outcome counters itself (collect_flags_kernel's job) */,
                                  const TieOrder tie /* (distance, id) order of the result: vq_common.h */) {
-    __shared__ __attribute__((aligned(8))) int2 sel[4 * RV_C];      // {key bits, source}: one 8-byte LDS access per entry
+    constexpr int POOL = C + RV_RESCAN_MAX * SCAN_STREAM_ROWS;      // exact-scored rows per query
+    constexpr int TPR = 256 / C;                                   // threads staging one candidate row
+    static_assert(C == 32 || C == 64, "candidates re-scored exactly: 32 (k <= 20) or 64 (k <= 40)");
+    __shared__ __attribute__((aligned(8))) int2 sel[4 * C];      // {key bits, source}: one 8-byte LDS access per entry
     __shared__ float wave_floor[4];
     __shared__ float red[256];
-    __shared__ float cand_key[RV_C];
-    __shared__ int cand_src[RV_C];
-    __shared__ int cand_row[RV_POOL];
-    __shared__ float cand_dist[RV_POOL];
+    __shared__ float cand_key[C];
+    __shared__ int cand_src[C];
+    __shared__ int cand_row[POOL];
+    __shared__ float cand_dist[POOL];
     __shared__ float bound_rest_s, qnorm2_s, dk_s;
     __shared__ int resc_stream[RV_RESCAN_MAX];
     __shared__ int resc_n, state, pool_n, have_s, surv_n;
@@ -839,10 +843,10 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     const float* qv = queries + (size_t)q * dim;
 
     VQ_RS_STAMP(0);
-    // ---- 1. the best RV_C of the query's 2*streams keys, and a bound on all the others.  The keys (query-major: one contiguous
+    // ---- 1. the best C of the query's 2*streams keys, and a bound on all the others.  The keys (query-major: one contiguous
     //         run, L2-resident) are read TWICE instead of each thread keeping a sorted short list of its share: pass A takes each
     //         thread's largest key; T = the smallest, over the four waves, of the wave's 8th largest thread maximum, so at least
-    //         32 keys are >= T and the overall best RV_C are among them; pass B collects the keys >= T (a few dozen) and the
+    //         32 keys are >= T and the overall best C are among them; pass B collects the keys >= T (a few dozen) and the
     //         largest key below T.  (Stamps: the insertion lists cost ~30 instructions per key whenever ANY lane of the wave
     //         inserted — 23k cycles; ranking the 256 maxima against each other another ~10k.) ----
     constexpr int PF = 16, KEEP_ROUNDS = 2;
@@ -881,7 +885,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         // their translations ready, did not move step 3's 19k cycles: removed again.)
         float cur = mx, t8 = NEG;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < C / 4; ++r) {                  // the wave's (C / 4)-th largest: 4 waves x C / 4 = C keys reach the threshold
             t8 = wave64_max(cur);
             const unsigned long long holders = __ballot(cur == t8);
             if (holders && lane == (int)__builtin_ctzll(holders)) cur = NEG;      // (all -inf: lane 0 "retires", nothing changes; none only if every key is NaN)
@@ -895,7 +899,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
         if (lane == 0) red[wave] = s2;
     }
-    if (tid < RV_C) { cand_key[tid] = NEG; cand_src[tid] = -1; }
+    if (tid < C) { cand_key[tid] = NEG; cand_src[tid] = -1; }
     if (tid == 0) { resc_n = 0; state = 0; surv_n = 0; bound_rest_s = NEG; }
     __syncthreads();
     VQ_RS_STAMP(2);
@@ -932,7 +936,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
                         if (km >> (2 * u + w) & 1u) {
-                            if (pos < 4 * RV_C) sel[pos] = int2{(int)(w ? two[u].y : two[u].x), (int)((s + u * 256) * 2) + w};
+                            if (pos < 4 * C) sel[pos] = int2{(int)(w ? two[u].y : two[u].x), (int)((s + u * 256) * 2) + w};
                             ++pos;
                         }
                     }
@@ -954,7 +958,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
     __syncthreads();
     {
-        const int ns = min(surv_n, 4 * RV_C);                                // more keys than the list holds reach the threshold: flagged in step 4
+        const int ns = min(surv_n, 4 * C);                                // more keys than the list holds reach the threshold: flagged in step 4
         if (tid < ns) {
             const float vi = __builtin_bit_cast(float, sel[tid].x); const int si = sel[tid].y;
             int rank = 0;
@@ -975,12 +979,12 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
                 const float vj = __builtin_bit_cast(float, e.x);
                 rank += (vj > vi) || (vj == vi && e.y < si);
             }
-            if (rank < RV_C) { cand_key[rank] = vi; cand_src[rank] = si; }
-            if (rank == RV_C) bound_rest_s = vi;
+            if (rank < C) { cand_key[rank] = vi; cand_src[rank] = si; }
+            if (rank == C) bound_rest_s = vi;
         }
     }
     __syncthreads();
-    if (tid == 0)       // what was not selected: the (RV_C+1)-th collected key and every key below the threshold
+    if (tid == 0)       // what was not selected: the (C+1)-th collected key and every key below the threshold
         bound_rest_s = fmaxf(fmaxf(bound_rest_s, fmaxf(wave_floor[0], wave_floor[1])), fmaxf(wave_floor[2], wave_floor[3]));
     __syncthreads();
 
@@ -991,7 +995,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     //         Two passes: a random row of the fp32 master costs an address translation (~1.1k cycles each, served one after the
     //         other: 32 rows = 35k cycles, stamps), so the best `c1` candidates go first and the others follow only when the
     //         best key among them could still reach the k-th exact score found so far. ----
-    if (tid < RV_C) {
+    if (tid < C) {
         const int src = cand_src[tid];
         int row = -1;
         if (src >= 0 && cand_key[tid] > NEG) {
@@ -1002,29 +1006,29 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         cand_row[tid] = row;
         cand_dist[tid] = __builtin_inff();
     }
-    const int kk = k < RV_C ? k : RV_C;
-    const int c1 = min(RV_C, max(16, (k + 6 + 7) & ~7));        // first pass: k candidates and a margin, whole groups of 8
+    const int kk = k < C ? k : C;
+    const int c1 = min(C, max(16, (k + 6 + 7) & ~7));        // first pass: k candidates and a margin, whole groups of 8
     int limit = c1, my_rank = -1;                                // candidates re-scored; this thread's candidate among them by (distance, row)
-    extern __shared__ __attribute__((aligned(16))) float rs_dyn[];        // [RV_C][dim + 4] rows, then [dim] query
+    extern __shared__ __attribute__((aligned(16))) float rs_dyn[];        // [C][dim + 4] rows, then [dim] query
     const int ldr = dim + 4, d4 = dim >> 2;                                // +4 floats: rows on different LDS banks
-    float* qbuf = rs_dyn + RV_C * ldr;
-    static_assert(RV_C * 8 == 256, "eight threads stage one candidate row");
+    float* qbuf = rs_dyn + C * ldr;
+    static_assert(C * TPR == 256, "TPR threads stage one candidate row");
     for (int pass = 0; pass < 2; ++pass) {
-        const int lo = pass == 0 ? 0 : c1, hi = pass == 0 ? c1 : RV_C;
+        const int lo = pass == 0 ? 0 : c1, hi = pass == 0 ? c1 : C;
         if (tid == 0) dk_s = __builtin_inff();
         __syncthreads();                                         // cand_row / the decision of the previous pass visible
         {   // thread = (candidate c, eighth e): float4 e, e + 8, ... of the row, 16 loads issued before the first LDS store
-            const int c = tid >> 3, e = tid & 7;
+            const int c = tid / TPR, e = tid % TPR;
             const int r = c >= lo && c < hi ? cand_row[c] : -1;
             if (r >= 0) {
                 const float4* src = (const float4*)(rows + (size_t)r * dim);
                 float4* dst = (float4*)(rs_dyn + c * ldr);
-                for (int j0 = e; j0 < d4; j0 += 8 * 16) {
+                for (int j0 = e; j0 < d4; j0 += TPR * 16) {
                     float4 v[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = src[min(j0 + 8 * u, d4 - 1)];      // always loaded (clamped): a conditionally
+                    for (int u = 0; u < 16; ++u) v[u] = src[min(j0 + TPR * u, d4 - 1)];      // always loaded (clamped): a conditionally
 #pragma unroll                                                                              // written array goes to scratch
-                    for (int u = 0; u < 16; ++u) if (j0 + 8 * u < d4) dst[j0 + 8 * u] = v[u];
+                    for (int u = 0; u < 16; ++u) if (j0 + TPR * u < d4) dst[j0 + TPR * u] = v[u];
                 }
             }
         }
@@ -1054,7 +1058,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         }
         __syncthreads();
         limit = hi;
-        if (hi == RV_C) break;
+        if (hi == C) break;
         {   // the best key not re-scored yet bounds every candidate behind it (cand_key is sorted): can it still matter?
             const float dk = have_s >= kk ? dk_s : __builtin_inff();
             const float nextkey = cand_key[hi];
@@ -1064,7 +1068,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         }
     }
     VQ_RS_STAMP(6);
-    if (wave == 0) {       // the verdict: every lane tests its own candidate, lane 0 collects (was one thread walking all RV_C)
+    if (wave == 0) {       // the verdict: every lane tests its own candidate, lane 0 collects (was one thread walking all C)
         const int have = have_s;
         const float dk = have >= kk ? dk_s : __builtin_inff();
         const float sk = 1.0f - dk;
@@ -1072,10 +1076,10 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
         // a stream's 2nd key: its unseen rows are bounded only by it (candidates not re-scored lie below sk - eps: never set)
         const bool second = tid < limit && (cand_src[tid] & 1) && cand_key[tid] + eps >= sk;
         unsigned long long need = __ballot(second);
-        if (tid >= limit && tid < RV_C) cand_row[tid] = -1;    // not re-scored: not part of the pool
+        if (tid >= limit && tid < C) cand_row[tid] = -1;    // not re-scored: not part of the pool
         if (lane == 0) {
             int st = 0, nres = 0;
-            if (have < kk || surv_n > 4 * RV_C || !(qnorm2_s >= SCAN_Q2_MIN && qnorm2_s <= SCAN_Q2_MAX)) st = 2;      // (more keys tied at the selection threshold than the list holds; a query the fp16 bound does not cover)
+            if (have < kk || surv_n > 4 * C || !(qnorm2_s >= SCAN_Q2_MIN && qnorm2_s <= SCAN_Q2_MAX)) st = 2;      // (more keys tied at the selection threshold than the list holds; a query the fp16 bound does not cover)
             else {
                 if (!(bound_rest_s + eps < sk)) st = 2;            // a key outside the best C could still matter
                 if (st == 0) {
@@ -1096,7 +1100,7 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     // ---- 5. stream rescans (all 128 rows, exactly); candidates of a rescanned stream leave the pool ----
     const int nres = resc_n;
     if (nres > 0) {
-        if (tid < RV_C && cand_row[tid] >= 0) {
+        if (tid < C && cand_row[tid] >= 0) {
             for (int w = 0; w < nres; ++w) if ((cand_src[tid] >> 1) == resc_stream[w]) cand_row[tid] = -1;
         }
         for (int i = tid; i < nres * SCAN_STREAM_ROWS; i += 256) {
@@ -1104,10 +1108,10 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
             const int64_t r = scan3_row_of(resc_stream[which], local);
             int row = -1; float d = __builtin_inff();
             if (r < n_valid) { row = (int)r; d = 1.0f - ((dim & 31) == 0 ? exact_dot_chain_pf(rows + (size_t)r * dim, qv, dim) : exact_dot_chain(rows + (size_t)r * dim, qv, dim)); }   // _pf: eight 16-byte loads in flight per thread (a stream rescan was ~35 us of one-load-per-step round trips)
-            cand_row[RV_C + i] = row; cand_dist[RV_C + i] = d;
+            cand_row[C + i] = row; cand_dist[C + i] = d;
         }
     }
-    if (tid == 0) pool_n = RV_C + nres * SCAN_STREAM_ROWS;
+    if (tid == 0) pool_n = C + nres * SCAN_STREAM_ROWS;
     __syncthreads();
 
     VQ_RS_STAMP(8);
@@ -1139,5 +1143,12 @@ void rescore_verify_small_kernel(const uint32_t* __restrict__ keys, int64_t stre
     }
     VQ_RS_STAMP(9);
 }
+
+// k <= RV_K_SMALL: 32 candidates (what round 2 shipped, under its old name); RV_K_SMALL < k <= RV_K_SMALL64 on a one-query-at-a-time
+// search (the caller's k * 2 for a user k of 11 .. 20, video_search_system.py:297): 64 candidates — a lone workgroup has the CU's LDS
+// to itself (64 staged rows of 512 floats = 132 KB), where the wide-pool kernel above spends 0.06 ms on one query
+constexpr int RV_K_SMALL64 = 40;
+static const auto rescore_verify_small_kernel = rescore_verify_small_kernel_t<32>;
+static const auto rescore_verify_small64_kernel = rescore_verify_small_kernel_t<64>;
 
 }  // namespace vq

@@ -280,11 +280,15 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     (void)fast_rows; (void)fb_rows;                     // (launch_fallback derives the same geometry)
     VQ_TRY(reserve_buf(x->d_fb_partial, x->fbp_cap, std::max<int64_t>(fb_cap * fb_splits, (int64_t)FB_FAST_SLOTS * fast_splits) * k));
     const int ranges = (int)(n_pad / RANGE);
+    // k in (20, 40] from the streaming scan (the caller's k * 2 for a user k of 11 .. 20): the 64-candidate form of the single-query kernel
+    const bool small64 = ver == 3 && k > RV_K_SMALL && k <= RV_K_SMALL64 && x->dim <= 512 && !large_qpw4() && !(getenv("VQ_AMD_RESCORE_SMALL64") && atoi(getenv("VQ_AMD_RESCORE_SMALL64")) == 0);
     if (ver == 3) {
         static std::atomic<bool> attr3_set{false};
         if (!attr3_set) {
             VQ_HIP(hipFuncSetAttribute((const void*)rescore_verify_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (RV_C * (768 + 4) + 768) * 4));
+            VQ_HIP(hipFuncSetAttribute((const void*)rescore_verify_small64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (64 * (512 + 4) + 512) * 4));
             attr3_set = true;
         }
     }
@@ -359,7 +363,11 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
         {
             Prof p(x, I_RESCORE);
             const bool large = k > RV_K_SMALL;                  // k in (20, 64]: the wide candidate pool, whatever scan produced the keys
-            if (large && ver == 3 && !large_qpw4())
+            if (small64)             // k in (20, 40] on the streaming scan's keys: the one-workgroup-per-query kernel with 64 candidates
+                hipLaunchKernelGGL(rescore_verify_small64_kernel, dim3(cur), dim3(256), (size_t)(64 * (x->dim + 4) + x->dim) * 4, x->stream, x->d_keys, streams, q_pad, x->rows, n,
+                                   x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k, d_dist_out + q0 * k, x->d_flags + q0,
+                                   scan_eps_unit(x->dim) * x->row_norm_max, nq == 1 ? x->d_slots : nullptr, nq == 1 ? counters : nullptr, x->tie());
+            else if (large && ver == 3 && !large_qpw4())
                 hipLaunchKernelGGL(k > RV_K_MID ? rescore_verify_xlarge1_kernel : rescore_verify_large1_kernel, dim3(cur), dim3(256), 0, x->stream, x->d_keys, streams,
                                    q_pad, x->rows, n, x->dim, d_queries + q0 * x->dim, cur, k, d_ids + q0 * k,
                                    d_dist_out + q0 * k, x->d_flags + q0, 3, scan_eps_unit(x->dim) * x->row_norm_max, x->tie());
@@ -382,7 +390,7 @@ int search_fp16(vq_index* x, const float* d_queries, int nq, int k, int32_t* d_i
     // list and the fallback kernels size themselves from its length (all of them leave at once when it is empty), so
     // nothing here waits for the stream.  Rounds beyond the first exist only when more queries could be flagged than
     // one round's scratch holds.
-    if (!(ver == 3 && nq == 1 && k <= RV_K_SMALL))   // a single query's (small-k) re-score workgroup has written the list and the counters itself
+    if (!(ver == 3 && nq == 1 && (k <= RV_K_SMALL || small64)))   // a single query's (small-k) re-score workgroup has written the list and the counters itself
         hipLaunchKernelGGL(collect_flags_kernel, dim3(1), dim3(1024), 0, x->stream, x->d_flags, nq, x->d_slots, counters);
     VQ_HIP(hipGetLastError());
     if (host_sync) { x->fb_deferred = true; x->stats_pending = false; return 0; }
