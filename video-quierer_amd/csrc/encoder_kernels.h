@@ -167,6 +167,34 @@ struct EpiBiasResidualLnF32 {
     __device__ __forceinline__ void put_stats(int m, int n_wave0, float s1, float s2) const {
         part.ps[(size_t)(n_wave0 >> 6) * part.stride + m] = float2{s1, s2};
     }
+    // The 8-column form (gemm_mfma.h kWideRes) for the modes that touch the 16 + 16-bit stream: every access a 16-byte piece.
+    static constexpr bool kWideRes = (MODE & (RS_IN_SPLIT | RS_OUT_SPLIT)) != 0;
+    __device__ __forceinline__ void load8(int m, int n8, uint4& a, uint4& b) const {
+        const size_t o = (size_t)m * ldx + n8;
+        if constexpr (MODE & RS_IN_SPLIT) { a = *(const uint4*)(xh + o); b = *(const uint4*)(xl + o); }     // hi | lo
+        else { a = *(const uint4*)(x + o); b = *(const uint4*)(x + o + 4); }                                // the fp32 x
+    }
+    __device__ __forceinline__ void store_stats8(int m, int n8, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, uint4 a, uint4 b,
+                                                 float& s1, float& s2) const {
+        f32x4 r0, r1;
+        if constexpr (MODE & RS_IN_SPLIT) {
+            r0 = unpack4_f16(uint2{a.x, a.y}) + unpack4_f16(uint2{b.x, b.y});
+            r1 = unpack4_f16(uint2{a.z, a.w}) + unpack4_f16(uint2{b.z, b.w});
+        } else {
+            r0 = __builtin_bit_cast(f32x4, a); r1 = __builtin_bit_cast(f32x4, b);
+        }
+        const f32x4 y0 = r0 + v0 + b0, y1 = r1 + v1 + b1;
+        const size_t o = (size_t)m * ldx + n8;
+        if constexpr (MODE & RS_OUT_F32) { *(f32x4*)(x + o) = y0; *(f32x4*)(x + o + 4) = y1; }
+        const uint2 h0 = pack4_h<F16>(y0), h1 = pack4_h<F16>(y1);
+        *(uint4*)(xh + o) = uint4{h0.x, h0.y, h1.x, h1.y};
+        if constexpr (MODE & RS_OUT_SPLIT) {
+            const uint2 l0 = pack4_h<true>(y0 - unpack4_f16(h0)), l1 = pack4_h<true>(y1 - unpack4_f16(h1));
+            *(uint4*)(xl + o) = uint4{l0.x, l0.y, l1.x, l1.y};
+        }
+        s1 = ((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
+        s2 = ((y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3])) + ((y1[0] * y1[0] + y1[1] * y1[1]) + (y1[2] * y1[2] + y1[3] * y1[3]));
+    }
 };
 
 // Last block, CLS rows only: GEMM row m = image m -> residual row m*tokens; xh and the partials are COMPACT (row m)

@@ -95,6 +95,10 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;      // 8704 B per wave
 //              piece, 8 rows per wave instruction: store_ln8(m, n, v0, v1, bias0, bias1, aux0, aux1, stat).  Half as many
 //              store instructions and loop trips as the 4-column form; 8-byte stores per lane are issue-bound
 //              (MI355X_MICROARCH.md, 'attention epilogue store tail': 8x dwordx4 halves 16x dwordx2)
+//   kWideRes   [r04] the 8-column form for a residual epilogue that reads memory and emits row statistics (the 16 + 16-bit residual
+//              stream: four 8-byte accesses per four elements would be issue-bound): load8(m, n8, A, B) fetches the row segment as
+//              two 16-byte pieces one pass ahead, store_stats8(m, n8, v0, v1, bias0, bias1, A, B, s1, s2) stores and returns the
+//              lane's sum and sum of squares; the 8 lanes of a row segment are reduced by DPP adds (row8_sum)
 //   kRowIn     the functor consumes per-row (mean, rstd) prepared by the kernel prologue (row_stat(m), an LDS read) and a
 //              second per-column constant aux_at(n); its store is store_ln(m, n, acc, bias, aux, stat)
 template <class E, class = void> struct epi_row_stats : std::false_type {};
@@ -103,6 +107,8 @@ template <class E, class = void> struct epi_split_k : std::false_type {};
 template <class E> struct epi_split_k<E, std::void_t<decltype(E::kSplitK)>> : std::bool_constant<E::kSplitK> {};
 template <class E, class = void> struct epi_wide : std::false_type {};
 template <class E> struct epi_wide<E, std::void_t<decltype(E::kWide)>> : std::bool_constant<E::kWide> {};
+template <class E, class = void> struct epi_wide_res : std::false_type {};
+template <class E> struct epi_wide_res<E, std::void_t<decltype(E::kWideRes)>> : std::bool_constant<E::kWideRes> {};
 template <class E, class = void> struct epi_row_in : std::false_type {};
 template <class E> struct epi_row_in<E, std::void_t<decltype(E::kRowIn)>> : std::bool_constant<E::kRowIn> {};
 
@@ -178,6 +184,48 @@ __device__ __forceinline__ void wave_epilogue(char* strip, const f32x4 (&acc)[MI
                     const f32x4 v1 = *(const f32x4*)(strip + row * EPI_ROW_BYTES + wcol * 32 + 16);
                     const int m = m_wave0 + pass * 32 + row;
                     epi.store_ln8(m, n8, v0, v1, b0, b1, a0, a1, epi.row_stat(m));
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (epi_wide_res<Epi>::value) {
+        const int wrow = lane >> 3, wcol = lane & 7;
+        const int n8 = n_wave0 + wcol * 8;
+        const f32x4 b0 = epi.bias_at(n8), b1 = epi.bias_at(n8 + 4);
+        constexpr int FULLW = MI / 2;                                     // passes over 32 rows = 4 wave instructions of 8 rows
+        uint4 ldA[2][4], ldB[2][4];                                       // the row segments of a pass, fetched one pass ahead
+#pragma unroll
+        for (int it = 0; it < (FULLW > 0 ? 4 : 2); ++it) epi.load8(m_wave0 + it * 8 + wrow, n8, ldA[0][it], ldB[0][it]);
+        after_loads();
+#pragma unroll
+        for (int pass = 0; pass < (MI + 1) / 2; ++pass) {
+            const int blocks = (2 * pass + 1 < MI) ? 2 : 1;               // 16-row blocks in this pass (an odd MI ends on one)
+            if (pass + 1 < (MI + 1) / 2) {
+                const int nb = (2 * (pass + 1) + 1 < MI) ? 2 : 1;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    if (it < 2 * nb) epi.load8(m_wave0 + (pass + 1) * 32 + it * 8 + wrow, n8, ldA[(pass + 1) & 1][it], ldB[(pass + 1) & 1][it]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (h < blocks) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *(f32x4*)(strip + (h * 16 + frow) * EPI_ROW_BYTES + (ni * 16 + fgrp * 4) * 4) = acc[pass * 2 + h][ni];
+                }
+            // same wave, in-order LDS: the reads below see the writes above
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (it < 2 * blocks) {
+                    const int row = it * 8 + wrow;
+                    const f32x4 v0 = *(const f32x4*)(strip + row * EPI_ROW_BYTES + wcol * 32);
+                    const f32x4 v1 = *(const f32x4*)(strip + row * EPI_ROW_BYTES + wcol * 32 + 16);
+                    const int m = m_wave0 + pass * 32 + row;
+                    float s1, s2;
+                    epi.store_stats8(m, n8, v0, v1, b0, b1, ldA[pass & 1][it], ldB[pass & 1][it], s1, s2);
+                    s1 = row8_sum(s1); s2 = row8_sum(s2);                 // the 8 lanes of the row segment: fixed order
+                    if (wcol == 0) epi.put_stats(m, n_wave0, s1, s2);
                 }
             }
         }

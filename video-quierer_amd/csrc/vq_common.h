@@ -106,6 +106,14 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// ... over the 8 lanes of a half row (lanes 8j .. 8j + 7), the total in each of them: the first three steps of the above.
+__device__ __forceinline__ float row8_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
 // The largest x of a wave, in every lane: four DPP steps inside each row of 16, then the four row leaders by v_readlane
 // (no LDS crossbar).  x must not be NaN (v_max would drop it).
 __device__ __forceinline__ float wave64_max(float x) {
