@@ -849,6 +849,18 @@ def test_id_ranks_c_abi_contract(gpu_lib):
     gpu_lib.check(lib.vq_index_destroy(h))
 
 
+@pytest.mark.timeout(240)
+def test_search_fuzz_against_the_reference_order(gpu_lib):
+    """scripts/fuzz_search.py for 20 s on a fixed seed (its long runs: 3,035 random cases / 104,723 result lists, all identical):
+    index size, dimension, k, batch size, duplicate rows, id kind (row numbers / shuffled integers / the caller's strings) and
+    search mode at random; every list equals `sorted((distance, id) ...)[:k]` over the C oracle's distances, bit for bit."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_search.py"), "20", "4"],
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all identical" in r.stdout
+
+
 # ------------------------------------------------------------------ live system's brute-force index ("next" #2)
 def test_simple_video_index_matches_the_real_class(gpu_lib, tmp_path):
     """tests/golden/simple_index.npz holds what the REAL SimpleVideoIndex (video_search_overhaul.py:23-64, lifted out
