@@ -147,3 +147,48 @@ def test_local_checkpoint_directory_loads(tmp_path):
     with pytest.raises(KeyError):
         resolve_model(d16)
     assert load_tokenizer(str(tmp_path / "nowhere")) is None
+
+
+def test_identity_verdict_accepts_any_hashable_ids():
+    """ids are any hashable; a ragged mix makes np.asarray raise — the verdict "these ids are the row numbers"
+    must simply be no, and it is taken before anything is committed (hnsw.py add_batch / add_device)."""
+    from video_quierer_amd.indexes.hnsw import HNSWIndex
+    f = HNSWIndex._ids_are_rows
+    assert f(list(range(5, 9)), 5) and f(range(5, 9), 5) and f([np.int64(0), np.int32(1)], 0)
+    assert not f(list(range(5, 9)), 4) and not f(range(0, 8, 2), 0) and not f([], 0)
+    assert not f([("a", 1), ("b",)], 0) and not f(["x", ("y", 2)], 0) and not f([0, "1"], 0) and not f([0, 1.5], 0)
+    assert not f(["video0_0", "video0_1"], 0) and not f([1, 0], 0)
+
+
+def test_tie_order_ranks_follow_python_id_order(monkeypatch):
+    """hnsw.py _sync_tie_order without a device: the rank table handed to vq_index_set_id_ranks is the position of each row's id
+    in the order `sorted((distance, id))` falls back to — str by code point ("video0_10" < "video0_2"), ints numerically, tuples
+    as Python compares them; ids with no common order fall back to the host path (and clear the device's table)."""
+    from video_quierer_amd import _lib
+    from video_quierer_amd.indexes.hnsw import HNSWIndex
+    calls = []
+
+    class FakeLib:
+        def vq_index_set_id_ranks(self, h, ptr, n):
+            calls.append(None if n == 0 else [ptr[i] for i in range(n)])
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+
+    def ranks_for(ids):
+        idx = HNSWIndex.__new__(HNSWIndex)
+        idx._ids, idx._h, idx._tie_order = list(ids), None, "stale"
+        idx._sync_tie_order()
+        return idx._tie_order, calls[-1]
+
+    for ids in (["video0_2", "video0_10", "video1_0", "video0_1", "Video0_1", "vidéo", "video0_1\x00"],      # numpy's '<U' order must equal str's (NUL-terminated twin included)
+                [f"v{i % 7}_{i}" for i in range(200)],
+                [5, -3, 10**12, 0], [(1, "b"), (1, "a"), (0, "z")], [2.5, 1, 3]):
+        mode, got = ranks_for(ids)
+        order = sorted(range(len(ids)), key=ids.__getitem__)
+        want = [0] * len(ids)
+        for pos, r in enumerate(order):
+            want[r] = pos
+        assert mode == "device" and got == want, ids
+    mode, got = ranks_for([3, "a", 1])                  # no total order: the reference itself fails on such a tie
+    assert mode == "host" and got is None
