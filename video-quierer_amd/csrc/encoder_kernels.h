@@ -224,6 +224,7 @@ struct EpiLnH16 {
     uint16_t* out; int ldo; const float* c2; const float* c1; LnPartials part; int granules; float inv_h, eps;
     const float2* lds = nullptr; int m0 = 0;            // bound per workgroup by the kernel (epi_bind_rowstats)
     static constexpr bool kLoads = false, kRowIn = true, kWide = true;
+    static constexpr bool kNtStore = VQ_EPI_LN_NT_STORE == 1 || (VQ_EPI_LN_NT_STORE == 2 && GELU);      // 1: q|k|v and MLP outputs, 2: the MLP output only
     __device__ __forceinline__ f32x4 bias_at(int n) const { return ld4(c2 + n); }
     __device__ __forceinline__ f32x4 aux_at(int n) const { return ld4(c1 + n); }
     __device__ __forceinline__ f32x4 load(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -250,11 +251,8 @@ struct EpiLnH16 {
             if constexpr (GELU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * y));
             v[i] = y;
         }
-#if VQ_EPI_LN_NT_STORE
-        { typedef __attribute__((ext_vector_type(2))) unsigned int u32x2; const uint2 pk = pack4_h<F16>(v); __builtin_nontemporal_store(u32x2{pk.x, pk.y}, (u32x2*)(out + (size_t)m * ldo + n)); }
-#else
-        *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
-#endif
+        if constexpr (kNtStore) { typedef __attribute__((ext_vector_type(2))) unsigned int u32x2; const uint2 pk = pack4_h<F16>(v); __builtin_nontemporal_store(u32x2{pk.x, pk.y}, (u32x2*)(out + (size_t)m * ldo + n)); }
+        else *(uint2*)(out + (size_t)m * ldo + n) = pack4_h<F16>(v);
     }
     __device__ __forceinline__ void store_ln8(int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, f32x4 a0, f32x4 a1, float2 st) const {
 #pragma unroll
@@ -268,12 +266,12 @@ struct EpiLnH16 {
             v0[i] = y0; v1[i] = y1;
         }
         const uint2 lo = pack4_h<F16>(v0), hi = pack4_h<F16>(v1);
-#if VQ_EPI_LN_NT_STORE
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y}, (u32x4*)(out + (size_t)m * ldo + n));
-#else
-        *(uint4*)(out + (size_t)m * ldo + n) = uint4{lo.x, lo.y, hi.x, hi.y};
-#endif
+        if constexpr (kNtStore) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y}, (u32x4*)(out + (size_t)m * ldo + n));
+        } else {
+            *(uint4*)(out + (size_t)m * ldo + n) = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
     }
 };
 
