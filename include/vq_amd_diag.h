@@ -25,6 +25,9 @@ int vq_debug_gemm_ablate(int M, int N, int K, int kernel, int diag, int reps, fl
 /* Average launch time of the deep-prefetch 256x256 mainloop on random data and the clock (GHz) the chip holds inside
  * its K loop (d s_memtime / d s_memrealtime, median over workgroups). */
 int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz_median);
+/* The deep-prefetch mainloop as a 256 x 192 tile (a timing ablation: results are wrong) beside the 256 x 256 one: what a
+ * q|k|v-of-one-head tile would cost.  N counts 256-wide tile slots in both forms. */
+int vq_debug_gemm_narrow(int M, int N, int K, int narrow, int reps, float* ms_avg, float* ghz_median, float* loop_cycles_median);
 
 /* s_memtime stamps of workgroup 0 of that mainloop, four per phase (phase start, before the mid barrier, before the
  * MFMAs, after them): stamps[8 waves][512]. */

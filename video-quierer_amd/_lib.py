@@ -142,6 +142,7 @@ DIAG_SIGNATURES = {
     "vq_debug_gemm_stamps": (c_int, [c_int, c_int, c_int, c_int, POINTER(ctypes.c_uint64)]),
     "vq_debug_gemm_ablate": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]),
     "vq_debug_gemm_clock": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "vq_debug_gemm_narrow": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
     "vq_debug_gemm_stamps_deep": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "vq_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
 }

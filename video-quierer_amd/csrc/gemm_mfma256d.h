@@ -71,7 +71,10 @@ constexpr int G2D_STAMPS = 512;                    // per wave, CLOCK == 2 diagn
 constexpr int G2_ROWSTAT_BYTES = G2_BM * 8;      // (mean, rstd) per tile row behind the two K-tile buffers (kRowIn epilogues)
 
 template <bool IS_F16, class Epi, int CLOCK = 0 /* diagnostic builds: 1 = clock around the K loop, 2 = s_memtime stamps per phase */,
-          bool BUF = false /* LDS-DMA as buffer_load ... lds (descriptor + 32-bit lane offset + scalar K offset) instead of global_load_lds */>
+          bool BUF = false /* LDS-DMA as buffer_load ... lds (descriptor + 32-bit lane offset + scalar K offset) instead of global_load_lds */,
+          bool NARROW = false /* diagnostic TIMING ablation (wrong results): a 256 x 192 tile - every wave's second W sub-block is one MFMA
+                                 column tile instead of two (48 MFMAs, 20 fragment reads and 14 LDS-DMA pieces per K-tile and wave instead
+                                 of 64 / 24 / 16): what a q|k|v-of-one-head tile would cost in this mainloop */>
 __global__ __launch_bounds__(G2_THREADS, 2)
 void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
                         const uint16_t* __restrict__ W, int ldw,
@@ -142,6 +145,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         const int koff = kt * G2_BK;
         if constexpr (BUF) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][0]), 16, w_voff[hn][0], koff * 2, 0, VQ_GEMM_D_W_AUX);
+            if (!(NARROW && hn == 1))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_void_t*)(base + w_dst[hn][1]), 16, w_voff[hn][1], koff * 2, 0, VQ_GEMM_D_W_AUX);
         } else {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(w_src[hn][0] + koff), (lds_void_t*)(base + w_dst[hn][0]), 16, 0, 0);
@@ -177,6 +181,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
+                if (!(NARROW && hn == 1 && j == 1))
                 wf[hn][j][ks] = *(const frag*)(buf + w_base + (hn * 2 + j) * 2048 + slot[ks]);
     };
     auto mfma_quadrant = [&](int hm, int hn) {
@@ -187,6 +192,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
+                    if (!(NARROW && hn == 1 && j == 1))
                     acc[hm * 4 + i][hn * 2 + j] = op::run(wf[hn][j][ks], af[i][ks], acc[hm * 4 + i][hn * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -195,7 +201,9 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-#define VQ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define VQ_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// (n = pieces issued after the awaited unit; the NARROW ablation's W1 unit is one piece per wave, so every count that includes a W1 is one less)
+#define VQ_VMCNT(n) do { if constexpr (NARROW) { if (n == 8) VQ_VMCNT_(7); else if (n == 4) VQ_VMCNT_(3); else VQ_VMCNT_(n); } else VQ_VMCNT_(n); } while (0)
     // CLOCK == 2: four s_memtime stamps per phase (start, before the mid barrier, before the MFMAs, after them) kept in
     // the LDS behind the two K-tile buffers (the launch asks for 160 KiB then)
     unsigned long long* stamp_lds = (unsigned long long*)(smem + G2_LDS_BYTES);
@@ -279,6 +287,7 @@ void gemm_tn256d_kernel(const uint16_t* __restrict__ A, int lda,
     if (wr == 0) barrier();               // every wave executes the same number of barriers
     barrier();                            // both groups past their last fragment reads before LDS is reused
 #undef VQ_VMCNT
+#undef VQ_VMCNT_
     VQ_TOWER_STAMP(ts2);
     VQ_TOWER_REALTIME(tr2);
 

@@ -134,6 +134,53 @@ int vq_debug_gemm_clock(int M, int N, int K, int reps, float* ms_avg, float* ghz
     return 0;
 }
 
+// Diagnostic: the deep-prefetch mainloop as a 256 x 192 tile (timing ablation NARROW of gemm_tn256d_kernel: wrong results) beside
+// the real 256 x 256 one.  narrow = 0 / 1; N counts 256-wide tile slots either way (a narrow run of N = 3072 stands for 12 tiles of 192
+// columns = 2304).  Returns the average launch time, the clock held inside the K loop and the median K-loop cycles per workgroup.
+int vq_debug_gemm_narrow(int M, int N, int K, int narrow, int reps, float* ms_avg, float* ghz_median, float* loop_cycles_median) {
+    VQ_TRY(require_init());
+    VQ_CHECK(ms_avg && ghz_median && loop_cycles_median && reps > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0, "vq_debug_gemm_narrow: bad argument");
+    uint16_t *dA = nullptr, *dW = nullptr; float* dC = nullptr; unsigned long long* dS = nullptr;
+    const int wgs = (M / 256) * (N / 256);
+    VQ_HIP(hipMalloc(&dA, (size_t)M * K * 2)); VQ_HIP(hipMalloc(&dW, (size_t)N * K * 2)); VQ_HIP(hipMalloc(&dC, (size_t)M * N * 4));
+    VQ_HIP(hipMalloc(&dS, (size_t)wgs * 16));
+    std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t r = 4242;
+    for (auto& v : a16) { r = r * 1664525u + 1013904223u; v = __builtin_bit_cast(uint16_t, (_Float16)(((int)(r >> 8) % 2001 - 1000) * 1e-3f)); }
+    for (auto& v : w16) { r = r * 1664525u + 1013904223u; v = __builtin_bit_cast(uint16_t, (_Float16)(((int)(r >> 8) % 2001 - 1000) * 1e-3f)); }
+    VQ_HIP(hipMemcpy(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    typedef EpiStoreF32 E;
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<true, E, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    VQ_HIP(hipFuncSetAttribute((const void*)gemm_tn256d_kernel<true, E, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    hipEvent_t e0, e1;
+    VQ_HIP(hipEventCreate(&e0)); VQ_HIP(hipEventCreate(&e1));
+    auto once = [&]() {
+        if (narrow)
+            hipLaunchKernelGGL((gemm_tn256d_kernel<true, E, 1, true, true>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr, dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
+        else
+            hipLaunchKernelGGL((gemm_tn256d_kernel<true, E, 1, true, false>), dim3(wgs), dim3(G2_THREADS), G2_LDS_BYTES, nullptr, dA, K, dW, K, K, N / 256, E{dC, N}, 0, dS);
+    };
+    for (int i = 0; i < 3; ++i) once();
+    VQ_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) once();
+    VQ_HIP(hipEventRecord(e1, nullptr));
+    VQ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / reps;
+    std::vector<unsigned long long> st((size_t)wgs * 2);
+    VQ_HIP(hipMemcpy(st.data(), dS, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<float> ghz, cyc;
+    for (int i = 0; i < wgs; ++i) if (st[2 * i + 1]) { ghz.push_back((float)st[2 * i] / (float)st[2 * i + 1] * 0.1f); cyc.push_back((float)st[2 * i]); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    *ghz_median = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
+    *loop_cycles_median = cyc.empty() ? 0.f : cyc[cyc.size() / 2];
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dS);
+    return 0;
+}
+
 // Diagnostic: per-phase s_memtime stamps of workgroup 0 of the deep-prefetch mainloop (four per phase: phase start, before
 // the mid barrier, before the MFMAs, after the MFMAs), random operands, after `reps` back-to-back launches.
 int vq_debug_gemm_stamps_deep(int M, int N, int K, int reps, unsigned long long* stamps /*[8][512]*/) {
