@@ -540,8 +540,11 @@ __device__ __forceinline__ uint4 ld16_att(const uint16_t* p) {
 #endif
 }
 
+#ifndef VQ_ATT_WAVES_PER_SIMD
+#define VQ_ATT_WAVES_PER_SIMD 3
+#endif
 template <bool F16>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, VQ_ATT_WAVES_PER_SIMD)
 void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                           int tokens, int hidden, int heads) {
     __shared__ __attribute__((aligned(16))) uint16_t vlds[4][64 * 64];
