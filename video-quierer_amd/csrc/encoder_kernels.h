@@ -540,11 +540,8 @@ __device__ __forceinline__ uint4 ld16_att(const uint16_t* p) {
 #endif
 }
 
-#ifndef VQ_ATT_WAVES_PER_SIMD
-#define VQ_ATT_WAVES_PER_SIMD 3
-#endif
 template <bool F16>
-__global__ __launch_bounds__(256, VQ_ATT_WAVES_PER_SIMD)
+__global__ __launch_bounds__(256)          // (asked for 3 waves per SIMD it compiles to 117 registers without scratch - and runs the same 21.8 us)
 void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                           int tokens, int hidden, int heads) {
     __shared__ __attribute__((aligned(16))) uint16_t vlds[4][64 * 64];
