@@ -59,11 +59,12 @@ def test_gemm_auto_tail_split_is_exact(gpu_lib):
 
 
 def test_gemm_multi_tile_workgroups_are_exact(gpu_lib):
-    """Kernel 16 with three and two tiles of a tile row per workgroup (n = 768 / 512): the next tile's first K-tile lands in
-    buffer 0 while the epilogue of the current one still reads its strips — small integers make any mix-up visible."""
+    """Kernel 16 with three, two and four tiles of a tile row per workgroup (n = 768 / 512 / 1024; four is what ViT-L/14@336's
+    q|k|v GEMM takes when batches run concurrently): the next tile's first K-tile lands in buffer 0 while the epilogue of the
+    current one still reads its strips — small integers make any mix-up visible."""
     from video_quierer_amd.encoder import debug_gemm
     rng = np.random.default_rng(5)
-    for n in (768, 512):
+    for n in (768, 512, 1024):
         a = rng.integers(-4, 5, (512, 640)).astype(np.float32)
         w = rng.integers(-8, 9, (n, 640)).astype(np.float32)
         for f16 in (False, True):

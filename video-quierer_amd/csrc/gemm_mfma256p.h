@@ -365,8 +365,16 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
             // +0.5 % frames/s with three; qkv drops to 150 workgroups: -29 % alone, +0.6-0.9 % frames/s with three batches in flight —
             // the idle CUs belong to the other batches then).  Concurrent handles only: a lone batch keeps the
             // tail-split dispatch below.  $VQ_AMD_GEMM_MULTI=0 switches it off, VQ_AMD_GEMM=15 forces it everywhere.
-            if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= gemm_multi_min_wgs()) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0)
-                return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
+            if ((((force == 6 || force == 14) && gemm_use_multi() && tiles / 3 >= gemm_multi_min_wgs()) || force == 15) && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0) {
+                // [r04] FOUR tiles per workgroup where that fills the chip's 256 CUs better than three: ViT-L/14@336's q|k|v GEMM is 73 x 12
+                // tiles = 292 workgroups of three (two rounds, the second 14 % full) or 219 of four (one round, 86 % full).  $VQ_AMD_GEMM_TPW forces.
+                static const int tpw_env = [] { const char* e = getenv("VQ_AMD_GEMM_TPW"); return e ? atoi(e) : 0; }();
+                auto fill = [&](int t) { const int64_t w = tiles / t; return (double)w / (double)(((w + 255) / 256) * 256); };
+                int tpw = 3;
+                if ((N / G2_BN) % 4 == 0 && tiles / 4 >= gemm_multi_min_wgs() && fill(4) > fill(3) + 0.05) tpw = 4;
+                if (tpw_env >= 1 && (N / G2_BN) % tpw_env == 0) tpw = tpw_env;
+                return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, tpw);
+            }
             return launch_gemm_tn256d<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
         }
         return launch_gemm_tn<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
@@ -390,7 +398,7 @@ static int launch_gemm_auto(hipStream_t st, const uint16_t* A, int lda, const ui
     if (force == 15 && fits256 && lda % 64 == 0 && ldw % 64 == 0 && (N / G2_BN) % 3 == 0 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128)
         return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, 3);
     if (force == 16 && fits256 && lda % 64 == 0 && ldw % 64 == 0)          // tests: the multi-tile kernel on any shape that tiles
-        return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, (N / G2_BN) % 3 == 0 ? 3 : (N / G2_BN) % 2 == 0 ? 2 : 1);
+        return launch_gemm_tn256dm<IS_F16>(st, A, lda, W, ldw, M, N, K, epi, (N / G2_BN) % 3 == 0 ? 3 : (N / G2_BN) % 4 == 0 ? 4 : (N / G2_BN) % 2 == 0 ? 2 : 1);
     if (force == 14 || force == 15 || force == 16) force = 0;
 #ifdef VQ_GEMM_EXPERIMENTS
     if (force == 10) return launch_gemm_tn256f<IS_F16>(st, A, lda, W, ldw, M, N, K, epi);
