@@ -556,30 +556,45 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     typedef mfma_op<F16> op;
     typedef typename op::frag frag;
 
-    // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
+    // All 24 loads of the wave's q | k | v (19.2 KB) are issued back to back, UNCONDITIONALLY (row index clamped, the value
+    // replaced by zeros afterwards): written as `if (row < tokens) val = load` the compiler put every V load behind its own
+    // exec-mask branch and waited for it (s_waitcnt vmcnt(0)) before the LDS store — eight dependent trips to memory before the
+    // first K / Q load was even issued (the "20k of 25k cycles waiting" of the r02b stamps; 21.9 us per launch once q | k | v
+    // came from HBM).  [r04]
     uint16_t* vt = vlds[wave];
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+    const int last = tokens - 1;
+    uint4 vv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int id = it * 64 + lane, row = id >> 3, c = id & 7;
-        uint4 val = {0u, 0u, 0u, 0u};
-        if (row < tokens) val = ld16_att(base + 2 * hidden + (size_t)row * ld + c * 8);
-        *(uint4*)(vt + row * 64 + c * 8) = val;
+        vv[it] = ld16_att(base + 2 * hidden + (size_t)min(row, last) * ld + c * 8);
     }
-
     // K (A operand) and Q (B operand) fragments straight from global memory
     frag kf[4][2], qf[4][2];
+    uint4 kraw[4][2], qraw[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int row = t * 16 + r16;
+        const int row = min(t * 16 + r16, last);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
-            if (row < tokens) {
-                kv = ld16_att(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
-                qv = ld16_att(base + (size_t)row * ld + ks * 32 + g * 8);
-            }
-            kf[t][ks] = __builtin_bit_cast(frag, kv);
-            qf[t][ks] = __builtin_bit_cast(frag, qv);
+            kraw[t][ks] = ld16_att(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
+            qraw[t][ks] = ld16_att(base + (size_t)row * ld + ks * 32 + g * 8);
+        }
+    }
+    // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = it * 64 + lane, row = id >> 3, c = id & 7;
+        *(uint4*)(vt + row * 64 + c * 8) = row < tokens ? vv[it] : zero4;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool live = t * 16 + r16 < tokens;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[t][ks] = __builtin_bit_cast(frag, live ? kraw[t][ks] : zero4);
+            qf[t][ks] = __builtin_bit_cast(frag, live ? qraw[t][ks] : zero4);
         }
     }
 
