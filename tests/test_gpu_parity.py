@@ -229,6 +229,35 @@ def test_encoder_16_plus_16_bit_residual_stream(gpu_lib, b32_weights, golden_enc
             assert max(err.values()) <= COS_TOL and err["split"] <= 1.5 * err["f32"] + 2e-5
 
 
+def test_encoder_single_tile_attention_forms_agree(gpu_lib, b32_weights, golden_encoder, monkeypatch):
+    """[r04] ViT-B/32's 50-token attention runs in attention_tile_kernel<50> (compile-time T: descriptor-ranged loads, V by LDS-DMA
+    into a swizzled tile, dead key registers skipped, exp2 in the log2 domain); $VQ_AMD_ATTN=t64 selects the run-time-T kernel of
+    rounds 1-3.  Same MFMA operand layouts and accumulation order: the embeddings differ only by exp2(fma(s, log2e, -m log2e))
+    against exp(s - m) and an approximate reciprocal - well inside the fp16 operands' noise; both stay inside the golden tolerance.
+    Outlier channels and a ragged batch (padding rows of the GEMMs next to the last image) included."""
+    from video_quierer_amd.encoder import VitEncoder
+    from video_quierer_amd.weights import VIT_B_32
+    from conftest import outlier_weights
+    for W, gold, n in ((b32_weights, golden_encoder["embeddings"], 64), (outlier_weights(), None, 37)):
+        frames = synth_frames(n)
+        out = {}
+        for form in ("t64", "tile"):
+            monkeypatch.setenv("VQ_AMD_ATTN", form)
+            enc = VitEncoder(VIT_B_32, W, max_batch=64)
+            out[form] = enc.encode(frames)
+            enc.close()
+        monkeypatch.delenv("VQ_AMD_ATTN")
+        assert np.isfinite(out["tile"]).all()
+        d = float(np.abs(out["tile"] - out["t64"]).max())
+        print(f"compile-time-T attention vs run-time-T attention ({n} frames): max |delta embedding| = {d:.2e}")
+        assert d <= 3e-4, d
+        assert not np.array_equal(out["tile"], out["t64"])                 # (the switch does switch)
+        if gold is not None:
+            err = {m: float(np.abs(o @ gold.T - gold @ gold.T).max()) for m, o in out.items()}
+            print("max score error against transformers' fp32 pipeline:", err)
+            assert max(err.values()) <= COS_TOL and err["tile"] <= 1.5 * err["t64"] + 2e-5
+
+
 def test_shared_weight_handles(gpu_lib, b32_weights):
     """vq_encoder_create_shared: clones run on the parent's device weights with their own stream and workspace; results
     are bit-identical to the parent's (same kernels), concurrent use is safe, and either side may be closed first."""

@@ -556,45 +556,30 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
     typedef mfma_op<F16> op;
     typedef typename op::frag frag;
 
-    // All 24 loads of the wave's q | k | v (19.2 KB) are issued back to back, UNCONDITIONALLY (row index clamped, the value
-    // replaced by zeros afterwards): written as `if (row < tokens) val = load` the compiler put every V load behind its own
-    // exec-mask branch and waited for it (s_waitcnt vmcnt(0)) before the LDS store — eight dependent trips to memory before the
-    // first K / Q load was even issued (the "20k of 25k cycles waiting" of the r02b stamps; 21.9 us per launch once q | k | v
-    // came from HBM).  [r04]
+    // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
     uint16_t* vt = vlds[wave];
-    const uint4 zero4 = {0u, 0u, 0u, 0u};
-    const int last = tokens - 1;
-    uint4 vv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int id = it * 64 + lane, row = id >> 3, c = id & 7;
-        vv[it] = ld16_att(base + 2 * hidden + (size_t)min(row, last) * ld + c * 8);
+        uint4 val = {0u, 0u, 0u, 0u};
+        if (row < tokens) val = ld16_att(base + 2 * hidden + (size_t)row * ld + c * 8);
+        *(uint4*)(vt + row * 64 + c * 8) = val;
     }
+
     // K (A operand) and Q (B operand) fragments straight from global memory
     frag kf[4][2], qf[4][2];
-    uint4 kraw[4][2], qraw[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int row = min(t * 16 + r16, last);
+        const int row = t * 16 + r16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            kraw[t][ks] = ld16_att(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
-            qraw[t][ks] = ld16_att(base + (size_t)row * ld + ks * 32 + g * 8);
-        }
-    }
-    // V tile -> LDS (rows >= tokens zero-filled: P is 0 there but 0*garbage may be NaN)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int id = it * 64 + lane, row = id >> 3, c = id & 7;
-        *(uint4*)(vt + row * 64 + c * 8) = row < tokens ? vv[it] : zero4;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const bool live = t * 16 + r16 < tokens;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[t][ks] = __builtin_bit_cast(frag, live ? kraw[t][ks] : zero4);
-            qf[t][ks] = __builtin_bit_cast(frag, live ? qraw[t][ks] : zero4);
+            uint4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
+            if (row < tokens) {
+                kv = ld16_att(base + hidden + (size_t)row * ld + ks * 32 + g * 8);
+                qv = ld16_att(base + (size_t)row * ld + ks * 32 + g * 8);
+            }
+            kf[t][ks] = __builtin_bit_cast(frag, kv);
+            qf[t][ks] = __builtin_bit_cast(frag, qv);
         }
     }
 
@@ -683,6 +668,179 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
                 *(uint2*)(out + ((size_t)img * tokens + qrow) * hidden + head * 64 + dt * 16 + g * 4) =
                     pack4_h<F16>(v);
             }
+        }
+    }
+}
+
+// ---- single-tile attention, T a compile-time constant: the instruction diet ----
+// attention_t64_kernel above is not bound by memory but by instruction ISSUE: 9,216 (image, head) units on 1,024 SIMDs = 9 units
+// per SIMD, and a unit was ~1,500 instructions (176 selects zeroing / masking padded rows, 128 accumulator-register reads because
+// the MFMAs were compiled to their AGPR form, ~130 instructions of 64-bit address arithmetic, a sub + mul + exp per score, exec
+// branches around 16 stores): 9 x ~5k cycles = the 22 us it ran in, whatever the loads did.  This form does the same arithmetic in
+// ~1/3 of the instructions:  [r04]
+//   * q | k | v through ONE buffer descriptor per wave whose range ends with the last token's V slice: rows past the sequence read
+//     as zeros and stores of query rows past it are dropped by the range check — no clamps, selects or exec masks;
+//   * V goes global -> LDS by buffer_load ... lds (7 instructions, no registers), the 16-byte chunks of a row XOR-swizzled by the
+//     row pair so that the transposed fragment reads spread over all banks (row-major 128-byte rows were an 8-way conflict);
+//   * T is a template parameter: scores of key positions no lane holds a live key for are never computed on (for T = 50 the
+//     fourth key tile has 2 live registers of 16: 14 exponentials per query column instead of 16), p = exp2(fma(s, log2 e, -m log2 e));
+//   * asked for two waves per SIMD the MFMAs compile to their VGPR form (no v_accvgpr_read).
+// Same operand layouts as attention_t64_kernel (S^T = K Q^T, P^T the B operand of O^T = V^T P^T); no workgroup barrier: every LDS
+// byte a wave reads was written by its own LDS-DMA.
+__device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0);
+    return uint4{v[0], v[1], v[2], v[3]};
+}
+template <bool F16, int T>
+__global__ __launch_bounds__(256, 2)
+void attention_tile_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int hidden, int heads) {
+    static_assert(T >= 17 && T <= 64, "single key tile of 64");
+    __shared__ __attribute__((aligned(1024))) uint16_t vlds[4][64 * 64];
+    typedef mfma_op<F16> op;
+    typedef typename op::frag frag;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hgroups = heads >> 2;
+    const int img = blockIdx.x / hgroups;
+    const int head = (blockIdx.x - img * hgroups) * 4 + wave;
+    const int ld = 3 * hidden;
+    const int r16 = lane & 15, g = lane >> 4;
+    // ranges: q | k | v of this image from this head's first column up to the end of the last token's V slice; the output likewise
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(qkv + (size_t)img * T * ld + head * 64), 0, ((T - 1) * ld + 2 * hidden + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(out + (size_t)img * T * hidden + head * 64), 0, ((T - 1) * hidden + 64) * 2, 0x00020000);
+    uint16_t* vt = vlds[wave];
+
+    // K (A operand) and Q (B operand) fragments: lane (r16, g) holds row 16 t + r16, dims 32 ks + 8 g .. + 8
+    const int row_bytes = ld * 2;
+    const int kq_off = r16 * row_bytes + g * 16;
+    uint4 kraw[4][2], qraw[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = kq_off + t * 16 * row_bytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kraw[t][ks] = buf_ld16(src, o + hidden * 2, ks * 64);
+            qraw[t][ks] = buf_ld16(src, o, ks * 64);
+        }
+    }
+    // V tile -> LDS, rows of 128 bytes; the lane that fills physical chunk c of row r fetches logical chunk c ^ (((r >> 1) & 3) << 1).
+    // Rows from the last partly live 8-row piece on are zero-filled first (P is 0 there, but 0 * stale LDS may be NaN).
+    constexpr int PIECES = (T + 7) / 8, ZROW0 = (T / 8) * 8;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ZROW0 < 64) {
+#pragma unroll
+        for (int i = 0; i < (64 - ZROW0) * 128 / 1024; ++i)
+            *(uint4*)(vt + ZROW0 * 64 + i * 512 + lane * 8) = uint4{0u, 0u, 0u, 0u};
+    }
+    const int v_off = (lane >> 3) * row_bytes + hidden * 4 + (((lane & 7) ^ (((lane >> 4) & 3) << 1)) << 4);
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+        if (it * 8 >= ZROW0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill of these rows has landed
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(vt + it * 512), 16, v_off + it * 8 * row_bytes, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load of the unit is in flight before the first MFMA waits for one (the scheduler had
+                                         // moved the V pieces behind the first K / Q waits: a second trip to memory)
+
+    frag kf[4][2], qf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[t][ks] = __builtin_bit_cast(frag, kraw[t][ks]);
+            qf[t][ks] = __builtin_bit_cast(frag, qraw[t][ks]);
+        }
+    // S^T[mt][nt]: lane holds keys 16 mt + 4 g + r (r = register), query 16 nt + r16.  Key tiles past the sequence are not computed.
+    constexpr int KT = (T + 15) / 16;          // key tiles with a live key
+    constexpr int FT = T / 16, R = T % 16;     // full tiles; live keys of the partial one
+    f32x4 s[4][4];
+#pragma unroll
+    for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = op::run(kf[mt][0], qf[nt][0], a);
+            a = op::run(kf[mt][1], qf[nt][1], a);
+            s[mt][nt] = a;
+        }
+    // softmax over keys, per query column, in the log2 domain
+    const float NEGBIG = -3.0e38f, L2E = 1.44269504088896341f;
+    float inv_sum[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float mx = NEGBIG;
+#pragma unroll
+        for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (mt == FT) {
+                    if (r >= R) continue;                                   // no lane holds a live key in this register
+                    if (4 * g + r >= R) s[mt][nt][r] = NEGBIG;
+                }
+                mx = fmaxf(mx, s[mt][nt][r]);
+            }
+        mx = rows4_max(mx);
+        const float m2 = mx * L2E;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < KT; ++mt) {
+            f32x4 e = s[mt][nt] * L2E - m2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = (mt == FT && r >= R) ? 0.f : __builtin_amdgcn_exp2f(e[r]);
+            s[mt][nt] = e;
+            acc += e;
+        }
+        inv_sum[nt] = __builtin_amdgcn_rcpf(rows4_sum((acc[0] + acc[1]) + (acc[2] + acc[3])));
+    }
+    // P^T fragments (B operand): k-slot j<4 -> tile 2s reg j ; j>=4 -> tile 2s+1 reg j-4
+    frag pf[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const uint2 plo = 2 * ss < KT ? pack4_h<F16>(s[2 * ss][nt]) : uint2{0u, 0u};
+            const uint2 phi = 2 * ss + 1 < KT ? pack4_h<F16>(s[2 * ss + 1][nt]) : uint2{0u, 0u};
+            pf[nt][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
+        }
+
+    __builtin_amdgcn_sched_barrier(0);                   // (nothing but arithmetic lies between the loads and this wait: unpinned, it floats up to them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V tile has landed (LDS-DMA counts in vmcnt)
+
+    // V^T fragments (A operand) by transposed LDS reads.  Lane i=4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+    // 4x16 block and receives column i of its 4 rows; the block's logical chunk 2 dt + (p >> 1) sits at physical chunk
+    // (2 (dt ^ sw) + (p >> 1)), sw = ((row >> 1) & 3) = (2 (g & 1) + (q >> 1)) & 3 for every row 32 ss + 16 h + 4 g + q this lane reads.
+    const int q4 = r16 >> 2, p4 = r16 & 3;
+    const int sw = (2 * (g & 1) + (q4 >> 1)) & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int o_off = (r16 * hidden + g * 4) * 2;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const uint16_t* vrow = vt + (4 * g + q4) * 64 + ((dt ^ sw) << 4) + p4 * 4;
+        f32x4 o[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            if (2 * ss >= KT) continue;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss) * 64));
+            s16x4 hi = {0, 0, 0, 0};
+            if (2 * ss + 1 < KT) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss + 16) * 64));
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const frag vf = __builtin_bit_cast(frag, both);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) o[nt] = op::run(vf, pf[nt][ss], o[nt]);
+        }
+        // O^T: lane holds d = 16 dt + 4 g + r, query 16 nt + r16; rows past the sequence fall outside dst's range
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt * 16 >= T) continue;
+            const uint2 pk = pack4_h<F16>(o[nt] * inv_sum[nt]);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, dst, o_off + nt * 16 * hidden * 2 + dt * 32, 0, 0);
         }
     }
 }

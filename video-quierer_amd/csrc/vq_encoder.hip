@@ -87,6 +87,7 @@ struct vq_encoder {
     float* tok_emb = nullptr; int* d_ids = nullptr; int* d_rowidx = nullptr; int vocab = 0, eos_id = 0;
     bool attn_simple = false;   // $VQ_AMD_ATTN=simple: per-wave streaming attention (reference implementation of the wg one)
     bool attn_q64 = false;      // $VQ_AMD_ATTN=q64: 64 query rows per wave (the round-2 form) instead of 32 (A/B switch)
+    bool attn_t64 = false;      // $VQ_AMD_ATTN=t64: the run-time-T single-tile kernel where attention_tile_kernel<T> would run (A/B switch)
     bool prune_last = true;  // last block on CLS rows only (outputs unchanged)
     float patch_unscale = 1.0f;   // 2^-s: undoes the power-of-two scale on fp16 patch weights (EpiPatchEmbedF32)
     int f16_mask = 0;        // per-GEMM-group operand type, DT_* bits (set = fp16, clear = bf16): create flags / $VQ_AMD_DTYPE
@@ -326,6 +327,8 @@ int run_forward(vq_encoder* e, const uint8_t* d_frames, int n, int swap_rb, floa
                     const int q_tiles = cdiv(T, 64), q_groups = cdiv(q_tiles, 4);
                     hipLaunchKernelGGL((attention_stream_wg_kernel<F16, true>), dim3(n * c.heads * q_groups), dim3(256), 0, st,
                                        e->qkv, e->att, T, H, c.heads, q_tiles, q_groups);
+                } else if (T == 50 && c.heads % 4 == 0 && !e->attn_t64) {   // ViT-B/32 at 224^2: the compile-time-T form
+                    hipLaunchKernelGGL((attention_tile_kernel<F16, 50>), dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, H, c.heads);
                 } else if (T <= 64 && c.heads % 4 == 0) {
                     hipLaunchKernelGGL(attention_t64_kernel<F16>, dim3(n * (c.heads / 4)), dim3(256), 0, st, e->qkv, e->att, T, H,
                                        c.heads);
@@ -508,7 +511,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
 #endif
-    if (const char* at = getenv("VQ_AMD_ATTN")) { e->attn_simple = !strcmp(at, "simple"); e->attn_q64 = !strcmp(at, "q64"); }
+    if (const char* at = getenv("VQ_AMD_ATTN")) { e->attn_simple = !strcmp(at, "simple"); e->attn_q64 = !strcmp(at, "q64"); e->attn_t64 = !strcmp(at, "t64"); }
     if (const char* fl = getenv("VQ_AMD_FULL_LAST_LAYER")) e->prune_last = atoi(fl) == 0;
     e->f16_mask = dtype_mask_from(flags);
     e->cfg = c; e->tokens = tokens; e->patches = patches; e->grid = grid; e->patch_k = patch_k; e->max_batch = max_batch;
@@ -622,7 +625,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     #ifdef VQ_DIAG
     if (const char* gm = getenv("VQ_AMD_GEMM24")) e->gemm24_mask = atoi(gm);
 #endif
-    e->attn_simple = parent->attn_simple; e->attn_q64 = parent->attn_q64; e->prune_last = parent->prune_last;
+    e->attn_simple = parent->attn_simple; e->attn_q64 = parent->attn_q64; e->attn_t64 = parent->attn_t64; e->prune_last = parent->prune_last;
     e->rows_pad = round_up((int64_t)max_batch * e->tokens + (G5_BM - 1), 256);
     e->prow_pad = round_up((int64_t)max_batch * e->patches, 256);
     e->weights_owner = parent->weights_owner ? parent->weights_owner : parent->arena_owner;   // a clone of a clone still pins the original weights
