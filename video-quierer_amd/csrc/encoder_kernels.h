@@ -1013,7 +1013,7 @@ void attention_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restr
 // 3.33 -> 2.83 ms per step (0.126 -> 0.148 of the MFMA peak on the 577^2 count), 2,292 -> 2,338 frames/s.  NQ = 2 is
 // instantiated for the non-causal (image) tower only; $VQ_AMD_ATTN=q64 selects the 64-row form for A/B.
 template <bool F16, bool CAUSAL, int NQ = 4>
-__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2)
+__global__ __launch_bounds__(256, NQ == 2 ? 4 : 2)
 void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                 int tokens, int hidden, int heads, int q_tiles, int q_groups) {
     __shared__ __attribute__((aligned(16))) uint16_t klds[2][64 * 64];
@@ -1149,17 +1149,22 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                     mx = rows4_max(mx);
                     const float m_new = fmaxf(m_run[nt], mx * L2E);
                     alpha[j] = __builtin_amdgcn_exp2f(m_run[nt] - m_new);
-                    float sum = 0.f;
+                    // four scores at a time as vector expressions: the fma and the running sum compile to v_pk_fma_f32 / v_pk_add_f32
+                    // (two scores per instruction; as scalar code they were 32 + 34 of the ~310 instructions of a key step)  [r04]
+                    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 4; ++mt) {
+                        f32x4 e = sc[mt][j] * L2E - m_new;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mt][j][r], L2E, -m_new));
+                            float p = __builtin_amdgcn_exp2f(e[r]);
                             if (EDGE && sc[mt][j][r] <= NEGBIG) p = 0.f;
-                            sc[mt][j][r] = p;
-                            sum += p;
+                            e[r] = p;
                         }
-                    sum = rows4_sum(sum);
+                        sc[mt][j] = e;
+                        acc4 += e;
+                    }
+                    const float sum = rows4_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]));
                     l_run[nt] = l_run[nt] * alpha[j] + sum;
                     m_run[nt] = m_new;
                 }

@@ -144,10 +144,13 @@ __device__ __forceinline__ void rows_swap32(float x, float& a, float& b) {
     a = x; b = x;
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
+// (the maximum is taken inside the asm: fmaxf() on the asm's opaque outputs made the compiler canonicalise both of them first —
+// v_max_f32 x, x, x twice per step, 4 of the 8 instructions of a rows4_max)
 __device__ __forceinline__ float rows4_max(float x) {
-    float a, b;
-    rows_swap16(x, a, b); x = fmaxf(a, b);
-    rows_swap32(x, a, b); return fmaxf(a, b);
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\t"
+        "s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
 }
 __device__ __forceinline__ float rows4_sum(float x) {
     float a, b;
