@@ -687,6 +687,14 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 //   * asked for two waves per SIMD the MFMAs compile to their VGPR form (no v_accvgpr_read).
 // Same operand layouts as attention_t64_kernel (S^T = K Q^T, P^T the B operand of O^T = V^T P^T); no workgroup barrier: every LDS
 // byte a wave reads was written by its own LDS-DMA.
+// A operand of sixteen rows of ones: O^T gets a fifth d-tile whose every row is the column sum of P^T, i.e. the softmax
+// denominator of the probabilities AS ROUNDED to 16 bits - from the matrix pipe, which has slack in every attention kernel here,
+// instead of ~1.5 vector instructions per score (adds, the cross-row butterfly) on the pipe that bounds them.  [r04]
+template <bool F16>
+__device__ __forceinline__ typename mfma_op<F16>::frag ones_frag() {
+    if constexpr (F16) { const _Float16 o = (_Float16)1.0f; return f16x8{o, o, o, o, o, o, o, o}; }
+    else { const __bf16 o = (__bf16)1.0f; return bf16x8{o, o, o, o, o, o, o, o}; }
+}
 __device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0);
@@ -785,16 +793,13 @@ void attention_tile_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restric
             }
         mx = rows4_max(mx);
         const float m2 = mx * L2E;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < KT; ++mt) {
             f32x4 e = s[mt][nt] * L2E - m2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) e[r] = (mt == FT && r >= R) ? 0.f : __builtin_amdgcn_exp2f(e[r]);
             s[mt][nt] = e;
-            acc += e;
         }
-        inv_sum[nt] = __builtin_amdgcn_rcpf(rows4_sum((acc[0] + acc[1]) + (acc[2] + acc[3])));
     }
     // P^T fragments (B operand): k-slot j<4 -> tile 2s reg j ; j>=4 -> tile 2s+1 reg j-4
     frag pf[4][2];
@@ -806,6 +811,18 @@ void attention_tile_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restric
             const uint2 phi = 2 * ss + 1 < KT ? pack4_h<F16>(s[2 * ss + 1][nt]) : uint2{0u, 0u};
             pf[nt][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
         }
+    // the denominators: column sums of P^T by MFMA against rows of ones (ones_frag), while the V tile is still landing
+    {
+        const frag ones = ones_frag<F16>();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+                if (2 * ss < KT) d = op::run(ones, pf[nt][ss], d);
+            inv_sum[nt] = __builtin_amdgcn_rcpf(d[0]);
+        }
+    }
 
     __builtin_amdgcn_sched_barrier(0);                   // (nothing but arithmetic lies between the loads and this wait: unpinned, it floats up to them)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V tile has landed (LDS-DMA counts in vmcnt)
@@ -1062,9 +1079,12 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
     const float NEGBIG = -3.0e38f;
     const float L2E = 1.44269504088896341f;
     // running maximum in the log2 domain (score * log2 e): p = exp2(score * log2e - m2) is one fma + one v_exp
-    float m_run[NQ], l_run[NQ];
+    // the running denominators are a fifth d-tile of the O^T accumulators (ones_frag): rescaled with them, read at the end
+    float m_run[NQ];
+    f32x4 osum[NQ];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) { m_run[j] = NEGBIG; l_run[j] = 0.f; }
+    for (int j = 0; j < NQ; ++j) { m_run[j] = NEGBIG; osum[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const frag ones = ones_frag<F16>();
 
     const int all_k_tiles = (tokens + 63) / 64;
     const int last_q_tile = min(q_tiles - 1, qg * 4 + 3);
@@ -1149,9 +1169,8 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                     mx = rows4_max(mx);
                     const float m_new = fmaxf(m_run[nt], mx * L2E);
                     alpha[j] = __builtin_amdgcn_exp2f(m_run[nt] - m_new);
-                    // four scores at a time as vector expressions: the fma and the running sum compile to v_pk_fma_f32 / v_pk_add_f32
-                    // (two scores per instruction; as scalar code they were 32 + 34 of the ~310 instructions of a key step)  [r04]
-                    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+                    // four scores at a time as a vector expression: the fma compiles to v_pk_fma_f32 (two scores per instruction;
+                    // as scalar code it was 32 of the ~310 instructions of a key step).  No running sum: osum  [r04]
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
                         f32x4 e = sc[mt][j] * L2E - m_new;
@@ -1162,10 +1181,7 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                             e[r] = p;
                         }
                         sc[mt][j] = e;
-                        acc4 += e;
                     }
-                    const float sum = rows4_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]));
-                    l_run[nt] = l_run[nt] * alpha[j] + sum;
                     m_run[nt] = m_new;
                 }
                 // the running maximum settles after the first tiles: rescale the accumulators only when some row's moved
@@ -1177,6 +1193,8 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                             f32x4& oo = o[dt][2 * hh + j];
                             oo[0] *= alpha[j]; oo[1] *= alpha[j]; oo[2] *= alpha[j]; oo[3] *= alpha[j];
                         }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) osum[2 * hh + j][0] *= alpha[j];       // (its four registers hold the same sum: one is read)
                 }
                 frag pf[2][2];
 #pragma unroll
@@ -1185,6 +1203,7 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                     for (int ss = 0; ss < 2; ++ss) {
                         const uint2 plo = pack4_h<F16>(sc[2 * ss][j]), phi = pack4_h<F16>(sc[2 * ss + 1][j]);
                         pf[j][ss] = __builtin_bit_cast(frag, uint4{plo.x, plo.y, phi.x, phi.y});
+                        osum[2 * hh + j] = op::run(ones, pf[j][ss], osum[2 * hh + j]);
                     }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
@@ -1213,7 +1232,7 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
 #pragma unroll
     for (int nt = 0; nt < NQ; ++nt) {
         const int qrow = q0 + nt * 16 + r16;
-        const float inv = 1.0f / l_run[nt];
+        const float inv = 1.0f / osum[nt][0];
         if (qrow < tokens) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
