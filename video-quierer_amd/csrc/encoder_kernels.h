@@ -1169,14 +1169,15 @@ void attention_stream_wg_kernel(const uint16_t* __restrict__ qkv, uint16_t* __re
                     mx = rows4_max(mx);
                     const float m_new = fmaxf(m_run[nt], mx * L2E);
                     alpha[j] = __builtin_amdgcn_exp2f(m_run[nt] - m_new);
-                    // four scores at a time as a vector expression: the fma compiles to v_pk_fma_f32 (two scores per instruction;
-                    // as scalar code it was 32 of the ~310 instructions of a key step).  No running sum: osum  [r04]
+                    // p = exp2(s log2e - m); no running sum: osum  [r04]
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
-                        f32x4 e = sc[mt][j] * L2E - m_new;
+                        f32x4 e;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float p = __builtin_amdgcn_exp2f(e[r]);
+                            float a = __builtin_fmaf(sc[mt][j][r], L2E, -m_new);
+                            asm volatile("" : "+v"(a));          // plain v_fma_f32 (2.8 cycles): paired into v_pk_fma_f32 (4.9 for two) the step measured 1 % slower
+                            float p = __builtin_amdgcn_exp2f(a);
                             if (EDGE && sc[mt][j][r] <= NEGBIG) p = 0.f;
                             e[r] = p;
                         }
