@@ -451,6 +451,9 @@ def main():
         return rehearse_cpu(args)
     if args.dtype is None:
         args.dtype = "fp16"          # the library default (encoder.DEFAULT_COMPUTE_DTYPE): every GEMM group on fp16 MFMA operands
+    # room for the streams of a multi-rank run (3 encode + 1 exchange + the index's + RCCL's own) beside the runtime's default of 4
+    # hardware queues per process; read by the HIP runtime when it initialises (measured equal at N = 1: 105.3k vs 105.1k frames/s)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -465,11 +468,36 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("VQ_BENCH_BACKEND", "nccl")
+    # One torch-owned HIP stream per batch in flight and the exchange's collective stream, created AND used before any RCCL
+    # communicator exists in the process (torch's, made eagerly by init_process_group(device_id=...), or the library's): the runtime
+    # maps streams onto a few hardware queues in the order they first carry work, and with a communicator's internal streams ahead of
+    # them two of the three encode streams shared a queue - an event wait of one then holds the other's kernels back.  Measured on
+    # one GPU with a ONE-rank communicator ($VQ_BENCH_REHEARSE_NATIVE): 96.0k frames/s with the communicator made first and never
+    # used, 92-94k with its gathers as well (per batch or per 8 batches alike), 104.7-105.8k with the streams first - what a run
+    # without any communicator gives (105.0k), and what GPU_MAX_HW_QUEUES=2 takes away from that one (95.8k).
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    xchg_stream = torch.cuda.Stream(device=dev)          # the exchange's one collective stream (Exchange below)
+    if os.environ.get("VQ_BENCH_STREAMS_FIRST", "1") != "0":
+        for s_ in streams + [xchg_stream]:
+            with torch.cuda.stream(s_):
+                torch.zeros(8, device=dev).add_(1)
+        torch.cuda.synchronize(dev)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("VQ_BENCH_REHEARSE_NATIVE") == "4":
+        # rehearsal: torch's own RCCL communicator as a multi-rank run has it (made eagerly, used once), in a world of one
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+        t_ = torch.ones(4, device=dev)
+        dist.all_reduce(t_)
+        torch.cuda.synchronize(dev)
 
     from video_quierer_amd import _lib
     from video_quierer_amd.encoder import VitEncoder
@@ -489,13 +517,22 @@ def main():
             comm = bring_up_native(dist, torch, dev, lambda: Comm.from_torch_distributed(local),
                                    float(os.environ.get("VQ_BENCH_COMM_DEADLINE", "120")))
             exchange = "libvq_amd vq_comm_* over RCCL %d" % comm.rccl_version()
+    # rehearsal switch (not used by the driver): a ONE-rank native communicator at N = 1, so that the timed step's exchange code
+    # (collective stream, events, vq_allgather_rows over a real RCCL communicator) runs on a one-GPU box
+    # (= 2: the communicator exists but nothing is exchanged; = 3: the exchange's buckets and events with a plain device copy in
+    # place of the collective - the two halves of what = 1 costs, measured apart; = 4: as 1, beside torch's own one-rank RCCL group)
+    rehearse_mode = int(os.environ.get("VQ_BENCH_REHEARSE_NATIVE", "0")) if world == 1 else 0
+    rehearse_native = rehearse_mode in (1, 3, 4)
+    if rehearse_mode in (1, 2, 4):
+        from video_quierer_amd.comm import Comm
+        comm = Comm.single(local)
+        exchange = "libvq_amd vq_comm_* over RCCL %d [one-rank rehearsal]" % comm.rccl_version()
+    gather = world > 1 or rehearse_native
     cfg = VIT_L_14_336 if args.model == "l14" else VIT_B_32
     flop_per_frame = 2 * cfg.macs_per_frame()
     weights = seeded_weights(cfg, 1234)
     # one encoder handle per in-flight batch, each on its own torch-owned HIP stream (torch owns it so the
     # RCCL all-gather of that batch's embeddings is ordered after the encode without a host sync)
-    nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     conc = nstreams > 1 if os.environ.get("VQ_BENCH_CONCURRENT") is None else os.environ["VQ_BENCH_CONCURRENT"] == "1"
     # the handles share ONE device copy of the weights (vq_encoder_create_shared): each in-flight batch only adds a workspace
     encs = [VitEncoder(cfg, weights, max_batch=BATCH, device=local, compute_dtype=args.dtype, concurrent=conc)]
@@ -510,23 +547,88 @@ def main():
     pool = [torch.randint(0, 255, (BATCH, cfg.image_size, cfg.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
             for _ in range(4)]
     embs = [torch.empty((BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) for _ in range(nstreams)]
-    gath = [torch.empty((world * BATCH, cfg.proj_dim), dtype=torch.float32, device=dev) if world > 1 else None
-            for _ in range(nstreams)]
     emb = embs[0]
     torch.cuda.synchronize(dev)
+
+    # The exchange of the data path: every rank's embeddings reach every rank, in rank (= frame shard) order.
+    # Fewer, larger collectives: G consecutive batches of a rank fill a bucket of G x BATCH rows, ONE all-gather moves it
+    # ($VQ_BENCH_GATHER_STEPS, default 8: 4 MB per rank at ViT-B/32; per-batch gathers of 0.5 MB cost 8-12 % of the encode rate
+    # even with a one-rank communicator - each is a separate tiny device operation with system-scope fences between the GEMMs
+    # of the batches in flight).  Two buckets alternate.  Every collective goes onto ONE stream, in bucket order (the batches in
+    # flight live on nstreams streams; whether RCCL orders one communicator's operations across user streams by itself is not
+    # something a one-GPU box can test, so nothing here depends on it): a gather waits for its bucket's encodes by events, an
+    # encode into a bucket waits for that bucket's previous gather.  fence() flushes the partly filled bucket first, so every
+    # embedding produced inside a timed region is also gathered inside it.
+    class Exchange:
+        def __init__(self):
+            self.G = max(1, int(os.environ.get("VQ_BENCH_GATHER_STEPS", "8")))
+            rows = self.G * BATCH
+            self.local = [torch.empty((rows, cfg.proj_dim), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.all = [torch.empty((world * rows, cfg.proj_dim), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.stream = xchg_stream
+            self.ev_enc = [[torch.cuda.Event() for _ in range(self.G)] for _ in range(2)]
+            self.ev_gat = [None, None]
+            self.b, self.slot, self.rows = 0, 0, 0          # the bucket being filled, its next slot, its rows so far
+            self.last_rows = [0, 0]
+            self.gathers = 0
+
+        def out(self, st, n):
+            """Where the next batch's embeddings go (a device pointer); the encode runs on stream st."""
+            if self.ev_gat[self.b] is not None:
+                st.wait_event(self.ev_gat[self.b])           # the bucket's previous gather has read it
+            return self.local[self.b][self.rows:].data_ptr()
+
+        def encoded(self, st, n):
+            self.ev_enc[self.b][self.slot].record(st)
+            self.slot += 1
+            self.rows += n
+            if self.slot == self.G or n != BATCH:
+                self.flush()
+
+        def flush(self):
+            if self.rows == 0:
+                return
+            b, rows = self.b, self.rows
+            for s_ in range(self.slot):
+                self.stream.wait_event(self.ev_enc[b][s_])
+            if comm is not None:
+                comm.all_gather_rows(self.local[b].data_ptr(), [rows] * world, cfg.proj_dim, self.all[b].data_ptr(), self.stream.cuda_stream)
+            elif world == 1:                                  # rehearsal mode 3
+                with torch.cuda.stream(self.stream):
+                    self.all[b][:rows].copy_(self.local[b][:rows])
+            else:
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(self.all[b][: world * rows], self.local[b][:rows])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.ev_gat[b], self.last_rows[b] = ev, rows
+            self.gathers += 1
+            self.b, self.slot, self.rows = b ^ 1, 0, 0
+
+        def check(self):
+            """After a fence: this rank's block of every gathered bucket is what it encoded, bit for bit."""
+            ok = True
+            for b in range(2):
+                r = self.last_rows[b]
+                if r and not (b == self.b and self.rows):
+                    ok = ok and bool(torch.equal(self.all[b][rank * r:(rank + 1) * r], self.local[b][:r]))
+            return {"own_block_bit_identical": ok, "gathers": self.gathers, "batches_per_gather": self.G, "collective_stream": True}
+
+    xchg = Exchange() if gather else None
 
     def step(i, n=None):
         j = i % nstreams
         n = BATCH if n is None else n
         with torch.cuda.stream(streams[j]):
-            encs[j].encode_device(pool[i % len(pool)].data_ptr(), n, embs[j].data_ptr())
-            if world > 1:
-                if comm is not None:
-                    comm.all_gather_rows(embs[j].data_ptr(), [n] * world, cfg.proj_dim, gath[j].data_ptr(), streams[j].cuda_stream)
-                else:
-                    dist.all_gather_into_tensor(gath[j][: world * n], embs[j][:n])
+            if xchg is None:
+                encs[j].encode_device(pool[i % len(pool)].data_ptr(), n, embs[j].data_ptr())
+            else:
+                encs[j].encode_device(pool[i % len(pool)].data_ptr(), n, xchg.out(streams[j], n))
+                xchg.encoded(streams[j], n)
 
     def fence():
+        if xchg is not None:
+            xchg.flush()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -599,6 +701,7 @@ def main():
     own_elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(own_elapsed)
     frames_per_s = world * args.steps * BATCH / elapsed
+    gather_check = xchg.check() if xchg is not None else None        # outside the timed region
 
     # one whole configs[1] job per rank: 50,000 frames = 195 batches of 256 + a ragged batch of 80
     sustained = None
@@ -642,9 +745,9 @@ def main():
                    "frames_per_step_per_gpu": BATCH, "global_batch": BATCH * world, "batches_in_flight": nstreams,
                    "weight_copies_per_gpu": 1,
                    "timed_frames": world * args.steps * BATCH,
-                   "parallelism": f"dp{world} (frame shards; all-gather of embeddings per step)" if world > 1 else "single GPU"},
+                   "parallelism": (f"dp{world} (frame shards; one all-gather of embeddings per {xchg.G} batches of a rank, on one collective stream)" if world > 1 else "single GPU")},
         "world": {"size": world, "backend": ("nccl = RCCL %s" % ".".join(map(str, torch.cuda.nccl.version()))) if world > 1 and backend == "nccl" else backend if world > 1 else None,
-                  "exchange": exchange, "ranks": ranks_info, "selfcheck": selfcheck},
+                  "exchange": exchange, "ranks": ranks_info, "selfcheck": selfcheck, "gather_check": gather_check},
         "sustained": sustained,
         "sustained_frames_per_s": sustained["frames_per_s"] if sustained else None,
         "encode_mfma_frac_whole_pass": frames_per_s / world * flop_per_frame / PEAK_BF16,
