@@ -684,7 +684,9 @@ void attention_t64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict
 //     row pair so that the transposed fragment reads spread over all banks (row-major 128-byte rows were an 8-way conflict);
 //   * T is a template parameter: scores of key positions no lane holds a live key for are never computed on (for T = 50 the
 //     fourth key tile has 2 live registers of 16: 14 exponentials per query column instead of 16), p = exp2(fma(s, log2 e, -m log2 e));
-//   * asked for two waves per SIMD the MFMAs compile to their VGPR form (no v_accvgpr_read).
+//   * asked for two waves per SIMD the MFMAs compile to their VGPR form (no v_accvgpr_read);
+//   * the V^T fragments are read so that a lane ends up with EIGHT consecutive head dimensions of a query row: 8 stores of 16 bytes per
+//     wave instead of 16 of 8 (the store tail was issue-bound: 17.9 -> 15.7 us per launch, the largest single step after the diet).
 // Same operand layouts as attention_t64_kernel (S^T = K Q^T, P^T the B operand of O^T = V^T P^T); no workgroup barrier: every LDS
 // byte a wave reads was written by its own LDS-DMA.
 // A operand of sixteen rows of ones: O^T gets a fifth d-tile whose every row is the column sum of P^T, i.e. the softmax
@@ -708,7 +710,6 @@ void attention_tile_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restric
     typedef mfma_op<F16> op;
     typedef typename op::frag frag;
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hgroups = heads >> 2;
@@ -827,37 +828,45 @@ void attention_tile_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restric
     __builtin_amdgcn_sched_barrier(0);                   // (nothing but arithmetic lies between the loads and this wait: unpinned, it floats up to them)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V tile has landed (LDS-DMA counts in vmcnt)
 
-    // V^T fragments (A operand) by transposed LDS reads.  Lane i=4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
-    // 4x16 block and receives column i of its 4 rows; the block's logical chunk 2 dt + (p >> 1) sits at physical chunk
-    // (2 (dt ^ sw) + (p >> 1)), sw = ((row >> 1) & 3) = (2 (g & 1) + (q >> 1)) & 3 for every row 32 ss + 16 h + 4 g + q this lane reads.
+    // V^T fragments (A operand) by transposed LDS reads.  Lane i = 4p + j of a 16-lane group: the lane (q, p) addresses row q and four
+    // columns c0(p) .. c0(p) + 3, and lane i receives column j of lane p's four for the group's 4 rows - which d-column an A row means
+    // is the reader's choice.  c0(p) = 32 a + 8 p + 4 b for the tile dt = 2 a + b: accumulator register r of lane (r16, g) then holds
+    // d = 32 a + 8 g + 4 b + r, i.e. the two tiles of a pair give a lane EIGHT consecutive d of a query row - one 16-byte store per
+    // (pair, query tile), 8 per wave instead of 16 of 8 bytes (the store tail of this shape is issue-bound: MI355X_MICROARCH.md).
+    // Logical 16-byte chunk 4 a + p of a row sits at physical chunk (4 a + p) ^ (sw << 1), sw = ((row >> 1) & 3) =
+    // (2 (g & 1) + (q >> 1)) & 3 for every row 32 ss + 16 h + 4 g + q this lane reads.
     const int q4 = r16 >> 2, p4 = r16 & 3;
     const int sw = (2 * (g & 1) + (q4 >> 1)) & 3;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const int o_off = (r16 * hidden + g * 4) * 2;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int o_off = (r16 * hidden + g * 8) * 2;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const uint16_t* vrow = vt + (4 * g + q4) * 64 + ((dt ^ sw) << 4) + p4 * 4;
-        f32x4 o[4];
+    for (int a = 0; a < 2; ++a) {
+        f32x4 o[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b) {
+            const uint16_t* vrow = vt + (4 * g + q4) * 64 + (((4 * a + p4) ^ (sw << 1)) << 3) + 4 * b;
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            if (2 * ss >= KT) continue;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss) * 64));
-            s16x4 hi = {0, 0, 0, 0};
-            if (2 * ss + 1 < KT) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss + 16) * 64));
-            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const frag vf = __builtin_bit_cast(frag, both);
+            for (int nt = 0; nt < 4; ++nt) o[b][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) o[nt] = op::run(vf, pf[nt][ss], o[nt]);
+            for (int ss = 0; ss < 2; ++ss) {
+                if (2 * ss >= KT) continue;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss) * 64));
+                s16x4 hi = {0, 0, 0, 0};
+                if (2 * ss + 1 < KT) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (32 * ss + 16) * 64));
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const frag vf = __builtin_bit_cast(frag, both);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) o[b][nt] = op::run(vf, pf[nt][ss], o[b][nt]);
+            }
         }
-        // O^T: lane holds d = 16 dt + 4 g + r, query 16 nt + r16; rows past the sequence fall outside dst's range
+        // O^T: lane holds d = 32 a + 8 g + 4 b + r, query 16 nt + r16; rows past the sequence fall outside dst's range
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (nt * 16 >= T) continue;
-            const uint2 pk = pack4_h<F16>(o[nt] * inv_sum[nt]);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, dst, o_off + nt * 16 * hidden * 2 + dt * 32, 0, 0);
+            const uint2 lo = pack4_h<F16>(o[0][nt] * inv_sum[nt]), hi = pack4_h<F16>(o[1][nt] * inv_sum[nt]);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, hi.x, hi.y}, dst, o_off + nt * 16 * hidden * 2 + a * 64, 0, 0);
         }
     }
 }
