@@ -69,7 +69,7 @@ struct vq_encoder {
     uint8_t* d_frames = nullptr;
     float *x = nullptr, *d_out = nullptr;
     uint16_t *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;      // h = xh: the residual stream rounded to 16 bits
-    uint16_t* xl = nullptr;                    // [r04] fp16(x - xh): with xh the residual stream at 16 + 16 bits (EpiBiasResidualLnF32 modes)
+    uint16_t* xl = nullptr;                    // [r04] the low half of the split residual stream, one fp8 byte per element (EpiBiasResidualLnF32 modes)
     bool split_resid = true;                   // $VQ_AMD_RESID=f32: every residual epilogue reads and writes the fp32 x (rounds 1-3; the A/B switch)
     float2* ps = nullptr;                      // LayerNorm row partials [hidden/64][rows_pad]
     uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned staging slots (lazy)
@@ -597,7 +597,7 @@ int vq_encoder_create_ex(const vq_vit_config* cfg, const float* const* weights, 
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
-    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>(VQ_RESID_XL8 ? ((size_t)e->rows_pad * H + 1) / 2 : (size_t)e->rows_pad * H);     // one byte per element (fp8 low half)
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * patch_k));
@@ -657,7 +657,7 @@ int vq_encoder_create_shared(vq_encoder* parent, int max_batch, int flags, vq_en
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * c.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
-    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>(VQ_RESID_XL8 ? ((size_t)e->rows_pad * H + 1) / 2 : (size_t)e->rows_pad * H);     // one byte per element (fp8 low half)
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>(std::max((size_t)e->rows_pad * M, (size_t)e->prow_pad * e->patch_k));
@@ -744,7 +744,7 @@ int vq_text_encoder_create(const vq_text_config* cfg, const float* const* weight
     e->x = A.take<float>((size_t)e->rows_pad * H);
     e->d_out = A.take<float>((size_t)max_batch * t.proj_dim);
     e->h = A.take<uint16_t>((size_t)e->rows_pad * H);
-    e->xl = A.take<uint16_t>((size_t)e->rows_pad * H);
+    e->xl = A.take<uint16_t>(VQ_RESID_XL8 ? ((size_t)e->rows_pad * H + 1) / 2 : (size_t)e->rows_pad * H);     // one byte per element (fp8 low half)
     e->qkv = A.take<uint16_t>((size_t)e->rows_pad * 3 * H);
     e->att = A.take<uint16_t>((size_t)e->rows_pad * H);
     e->mlp = A.take<uint16_t>((size_t)e->rows_pad * M);
