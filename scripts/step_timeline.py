@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""When does each of the K timed steps of bench.py's encode leg finish?  Three batches in flight on three streams (as bench.py), an event
+after every step; prints each step's completion time and the rate over the first / middle / last thirds - where a short run (the
+driver's --steps 20) loses against a long one.    python scripts/step_timeline.py [steps] [warmup]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from video_quierer_amd import _lib
+from video_quierer_amd.encoder import VitEncoder
+from video_quierer_amd.weights import VIT_B_32, seeded_weights
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B, NS = 256, 3
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+_lib.init(0)
+encs = [VitEncoder(VIT_B_32, seeded_weights(VIT_B_32, 1234), max_batch=B, device=0, compute_dtype="fp16", concurrent=True)]
+encs += [encs[0].clone(concurrent=True) for _ in range(NS - 1)]
+for e, s in zip(encs, streams):
+    e.set_stream(s.cuda_stream)
+pool = [torch.randint(0, 255, (B, 224, 224, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+embs = [torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(NS)]
+def step(i):
+    with torch.cuda.stream(streams[i % NS]):
+        encs[i % NS].encode_device(pool[i % 4].data_ptr(), B, embs[i % NS].data_ptr())
+for rep in range(3):
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    t0e = torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    t0 = time.perf_counter()
+    t0e.record(streams[0])
+    cpu = []
+    for i in range(K):
+        step(i)
+        evs[i].record(streams[i % NS])
+        cpu.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    done = [t0e.elapsed_time(e) for e in evs]
+    print(f"rep {rep}: {K} steps in {1e3 * wall:.2f} ms = {K * B / wall:.0f} frames/s; CPU enqueue of all steps done at {1e3 * cpu[-1]:.2f} ms")
+    print("   step done at (ms): " + " ".join(f"{d:.1f}" for d in done))
+    srt = sorted(done)
+    third = K // 3
+    for name, a, b in (("first", 0, third), ("middle", third, 2 * third), ("last", 2 * third, K)):
+        ta = srt[a - 1] if a else 0.0
+        print(f"   {name:6s} {b - a} steps: {(b - a) * B / (srt[b - 1] - ta) * 1e3:.0f} frames/s")
