@@ -27,10 +27,23 @@ embs = [torch.empty((B, 512), dtype=torch.float32, device=dev) for _ in range(NS
 def step(i):
     with torch.cuda.stream(streams[i % NS]):
         encs[i % NS].encode_device(pool[i % 4].data_ptr(), B, embs[i % NS].data_ptr())
+# optional: start the batches out of phase - stream j's first step waits j * STAGGER_MS behind a spin kernel
+STAGGER_MS = float(os.environ.get("STAGGER_MS", "0"))
+cyc_per_ms = 0.0
+if STAGGER_MS > 0:
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1_000_000); torch.cuda.synchronize()
+    a.record(); torch.cuda._sleep(10_000_000); b.record(); torch.cuda.synchronize()
+    cyc_per_ms = 10_000_000 / a.elapsed_time(b)
+    print(f"spin kernel: {cyc_per_ms:.0f} cycles per ms")
 for rep in range(3):
     for i in range(W):
         step(i)
     torch.cuda.synchronize()
+    if STAGGER_MS > 0:
+        for j in range(1, NS):
+            with torch.cuda.stream(streams[j]):
+                torch.cuda._sleep(int(j * STAGGER_MS * cyc_per_ms))
     t0e = torch.cuda.Event(enable_timing=True)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     t0 = time.perf_counter()
