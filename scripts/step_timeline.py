@@ -36,6 +36,16 @@ if STAGGER_MS > 0:
     a.record(); torch.cuda._sleep(10_000_000); b.record(); torch.cuda.synchronize()
     cyc_per_ms = 10_000_000 / a.elapsed_time(b)
     print(f"spin kernel: {cyc_per_ms:.0f} cycles per ms")
+# optional: keep the GPU busy with UNRELATED work (fp16 matmuls) for PREHEAT_S seconds before the first repetition: is a first
+# repetition slower because the chip is not in its steady state yet, or because the handles are not?
+PREHEAT_S = float(os.environ.get("PREHEAT_S", "0"))
+if PREHEAT_S > 0:
+    a_ = torch.randn((8192, 8192), dtype=torch.float16, device=dev); b_ = torch.randn((8192, 8192), dtype=torch.float16, device=dev)
+    t_ = time.perf_counter()
+    while time.perf_counter() - t_ < PREHEAT_S:
+        for _ in range(10):
+            a_ @ b_
+        torch.cuda.synchronize()
 for rep in range(3):
     for i in range(W):
         step(i)
