@@ -606,13 +606,23 @@ def main():
             self.b, self.slot, self.rows = b ^ 1, 0, 0
 
         def check(self):
-            """After a fence: this rank's block of every gathered bucket is what it encoded, bit for bit."""
-            ok = True
+            """After a fence: this rank's block of every gathered bucket is what it encoded, bit for bit; and every PEER's block of
+            the last gathered bucket sums (fp64, in row order) to what that peer says its local bucket sums to."""
+            ok, peers_ok = True, None
             for b in range(2):
                 r = self.last_rows[b]
                 if r and not (b == self.b and self.rows):
                     ok = ok and bool(torch.equal(self.all[b][rank * r:(rank + 1) * r], self.local[b][:r]))
-            return {"own_block_bit_identical": ok, "gathers": self.gathers, "batches_per_gather": self.G, "collective_stream": True}
+            if world > 1:
+                b = self.b ^ 1                                   # the bucket of the last flush
+                r = self.last_rows[b]
+                mine = float(self.local[b][:r].double().sum().item()) if r else 0.0
+                sums = [None] * world
+                dist.all_gather_object(sums, (r, mine))
+                peers_ok = all(rj == r for rj, _ in sums) and all(
+                    float(self.all[b][j * r:(j + 1) * r].double().sum().item()) == sj for j, (_, sj) in enumerate(sums)) if r else True
+            return {"own_block_bit_identical": ok, "peer_blocks_match_their_checksums": peers_ok, "gathers": self.gathers,
+                    "batches_per_gather": self.G, "collective_stream": True}
 
     xchg = Exchange() if gather else None
 

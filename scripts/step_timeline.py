@@ -41,11 +41,16 @@ if STAGGER_MS > 0:
 PREHEAT_S = float(os.environ.get("PREHEAT_S", "0"))
 if PREHEAT_S > 0:
     a_ = torch.randn((8192, 8192), dtype=torch.float16, device=dev); b_ = torch.randn((8192, 8192), dtype=torch.float16, device=dev)
+    big = torch.empty((2, 1 << 30), dtype=torch.uint8, device=dev)          # PREHEAT_KIND=copy: 1 GiB copies (HBM-bound) instead of matmuls
     t_ = time.perf_counter()
     while time.perf_counter() - t_ < PREHEAT_S:
         for _ in range(10):
-            a_ @ b_
+            if os.environ.get("PREHEAT_KIND") == "copy":
+                big[1].copy_(big[0])
+            else:
+                a_ @ b_
         torch.cuda.synchronize()
+    del big
 for rep in range(3):
     for i in range(W):
         step(i)
