@@ -205,9 +205,9 @@ int upload_layer(vq_encoder* e, LayerW& L, Arena& A, const float* const* weights
     L.w_fc1 = A.take<uint16_t>(M * H);
     L.c1_fc1 = A.take<float>(M);
     L.c2_fc1 = A.take<float>(M);
-    VQ_TRY(upload_folded(L.w_fc1, L.c1_fc1, L.c2_fc1, weights[wi], g2, b2, weights[wi + 1], M, H, e->f16_mask & DT_FC1));
+    VQ_TRY(upload_folded(L.w_fc1, L.c1_fc1, L.c2_fc1, weights[wi], g2, b2, weights[wi + 1], M, H, e->f16_mask & DT_FC1, VQ_GELU_FOLD ? QUICK_GELU_C : 1.0f));
     wi += 2;
-    L.w_fc2 = A.take<uint16_t>(H * M);    VQ_TRY(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2));
+    L.w_fc2 = A.take<uint16_t>(H * M);    VQ_TRY(upload_h16(L.w_fc2, weights[wi++], H * M, e->f16_mask & DT_FC2, VQ_GELU_FOLD ? 1.0f / QUICK_GELU_C : 1.0f));
     L.b_fc2 = A.take<float>(H);           VQ_TRY(upload_f32(L.b_fc2, weights[wi++], H));
     return 0;
 }
